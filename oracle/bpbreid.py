@@ -1,0 +1,161 @@
+"""Pure-torch CPU restatement of the BPBreID model (TEST INFRASTRUCTURE).
+
+Restates torchreid/models/bpbreid.py:15-279 (model + forward), :324-350 (after-pooling
+dim-reduce), :376-415 (pixel classifier, BN-neck classifier), :444-503 (pooling heads).
+The pooling heads deliberately keep the reference's algorithm -- materialise
+``masks[N,K,1,H,W] * feats[N,1,C,H,W]`` and reduce (bpbreid.py:459-468, 491-503) -- so that
+this module is an honest CPU baseline of what the reference executes.
+
+Config: any object exposing the ``cfg.model.bpbreid`` fields of
+torchreid/scripts/default_config.py:43-68 by attribute (yacs node, SimpleNamespace, ...).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .backbones import build_backbone
+
+GLOBAL, FOREGROUND, BACKGROUND, CONCAT_PARTS, PARTS = 'globl', 'foreg', 'backg', 'conct', 'parts'
+BN_GLOBAL, BN_FOREGROUND, BN_BACKGROUND, BN_CONCAT_PARTS, BN_PARTS = (
+    'bn_globl', 'bn_foreg', 'bn_backg', 'bn_conct', 'bn_parts')
+PIXELS = 'pixls'
+
+
+class _DimReduce(nn.Module):
+    """bpbreid.py:324-350: Linear(bias) + BN1d + ReLU; [N,K,C] inputs are flattened to N*K rows."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.layers = nn.Sequential(nn.Linear(cin, cout), nn.BatchNorm1d(cout), nn.ReLU())
+
+    def forward(self, x):
+        if x.dim() == 3:
+            n, k, _ = x.shape
+            return self.layers(x.flatten(0, 1)).view(n, k, -1)
+        return self.layers(x)
+
+
+class _PixelClassifier(nn.Module):
+    """bpbreid.py:376-385: BN2d(C) -> 1x1 conv (C -> K+1, with bias)."""
+
+    def __init__(self, c, k):
+        super().__init__()
+        self.bn = nn.BatchNorm2d(c)
+        self.classifier = nn.Conv2d(c, k + 1, 1)
+
+    def forward(self, x):
+        return self.classifier(self.bn(x))
+
+
+class _BNNeck(nn.Module):
+    """bpbreid.py:398-415: BN1d (bias frozen, :407) -> Linear without bias; returns (bn_feat, logits)."""
+
+    def __init__(self, cin, ncls):
+        super().__init__()
+        self.bn = nn.BatchNorm1d(cin)
+        self.bn.bias.requires_grad_(False)
+        self.classifier = nn.Linear(cin, ncls, bias=False)
+
+    def forward(self, x):
+        f = self.bn(x)
+        return f, self.classifier(f)
+
+
+def _masked_pool(feats, masks, weighted):
+    """bpbreid.py:458-468 (GAP over m*x) and :490-503 (GWAP: sum(m*x)/clamp(sum m, 1e-6))."""
+    prod = masks.unsqueeze(2) * feats.unsqueeze(1)              # [N,M,C,H,W] materialised, as the reference
+    if weighted:
+        s = prod.sum(dim=(-2, -1))
+        z = masks.sum(dim=(-2, -1)).clamp(min=1e-6).unsqueeze(-1)
+        return s / z
+    return prod.mean(dim=(-2, -1))
+
+
+class BPBreID(nn.Module):
+    def __init__(self, num_classes, cfg):
+        super().__init__()
+        m = cfg.model.bpbreid
+        self.cfg = m
+        self.K = m.masks.parts_num
+        self.backbone_appearance_feature_extractor = build_backbone(
+            m.backbone, num_classes, last_stride=m.last_stride,
+            enable_dim_reduction=(m.dim_reduce == 'before_pooling'),
+            dim_reduction_channels=m.dim_reduce_output)
+        c = self.backbone_appearance_feature_extractor.feature_dim
+        assert m.dim_reduce == 'after_pooling', 'oracle restates the default after_pooling path'
+        assert m.pooling == 'gwap' and m.normalization == 'identity'
+        d = m.dim_reduce_output
+        self.D = d
+        self.global_after_pooling_dim_reduce = _DimReduce(c, d)
+        self.foreground_after_pooling_dim_reduce = _DimReduce(c, d)
+        self.background_after_pooling_dim_reduce = _DimReduce(c, d)
+        self.parts_after_pooling_dim_reduce = _DimReduce(c, d)
+        self.pixel_classifier = _PixelClassifier(c, self.K)
+        self.global_identity_classifier = _BNNeck(d, num_classes)
+        self.background_identity_classifier = _BNNeck(d, num_classes)
+        self.foreground_identity_classifier = _BNNeck(d, num_classes)
+        self.concat_parts_identity_classifier = _BNNeck(self.K * d, num_classes)
+        if m.shared_parts_id_classifier:
+            self.parts_identity_classifier = _BNNeck(d, num_classes)
+        else:
+            self.parts_identity_classifier = nn.ModuleList([_BNNeck(d, num_classes) for _ in range(self.K)])
+
+    def forward(self, images, external_parts_masks=None):
+        m = self.cfg
+        feats = self.backbone_appearance_feature_extractor(images)
+        n, _, hf, wf = feats.shape
+        if m.learnable_attention_enabled:                         # bpbreid.py:146-148
+            pix_scores = self.pixel_classifier(feats)
+            probs = F.softmax(pix_scores, dim=1)
+        else:                                                     # bpbreid.py:149-155
+            pix_scores = None
+            probs = F.interpolate(external_parts_masks.to(feats.dtype), (hf, wf), mode='bilinear',
+                                  align_corners=True)
+        bg, parts = probs[:, 0], probs[:, 1:]
+        if not self.training and m.test_use_target_segmentation == 'hard':     # bpbreid.py:161-168
+            ext = F.interpolate(external_parts_masks, (hf, wf), mode='bilinear', align_corners=True)
+            target = ext[:, 1:].max(dim=1)[0] > ext[:, 0]
+            bg = ~target
+            parts = parts.clone()
+            parts[bg.unsqueeze(1).expand_as(parts)] = 1e-12
+        if not self.training and m.test_use_target_segmentation == 'soft':     # bpbreid.py:170-175
+            ext = F.interpolate(external_parts_masks, (hf, wf), mode='bilinear', align_corners=True)
+            parts = parts * ext[:, 1:]
+        fg = parts.max(dim=1)[0]                                  # bpbreid.py:178
+        binary = m.training_binary_visibility_score if self.training else m.testing_binary_visibility_score
+        if binary:                                                # bpbreid.py:182-187
+            onehot = F.one_hot(probs.argmax(dim=1), self.K + 1).permute(0, 3, 1, 2)
+            vis = onehot.amax(dim=(2, 3)).to(torch.bool)
+        else:
+            vis = probs.amax(dim=(2, 3))
+        bg_vis = vis[:, 0]
+        fg_vis = vis.amax(dim=1)                                  # includes the background column (:189)
+        parts_vis = vis[:, 1:]
+        glob_vis = torch.ones_like(fg_vis)
+
+        g = feats.mean(dim=(2, 3))                                # AdaptiveAvgPool2d(1), :195
+        f = _masked_pool(feats, fg.unsqueeze(1).to(feats.dtype), False).flatten(1, 2)
+        b = _masked_pool(feats, bg.unsqueeze(1).to(feats.dtype), False).flatten(1, 2)
+        p = _masked_pool(feats, parts, True)
+        g = self.global_after_pooling_dim_reduce(g)
+        f = self.foreground_after_pooling_dim_reduce(f)
+        b = self.background_after_pooling_dim_reduce(b)
+        p = self.parts_after_pooling_dim_reduce(p)
+        c = p.flatten(1, 2)
+        bn_g, s_g = self.global_identity_classifier(g)
+        bn_b, s_b = self.background_identity_classifier(b)
+        bn_f, s_f = self.foreground_identity_classifier(f)
+        bn_c, s_c = self.concat_parts_identity_classifier(c)
+        if m.shared_parts_id_classifier:                          # bpbreid.py:261-267
+            bn_p, s_p = self.parts_identity_classifier(p.flatten(0, 1))
+            bn_p, s_p = bn_p.view(n, self.K, -1), s_p.view(n, self.K, -1)
+        else:                                                     # bpbreid.py:268-277
+            outs = [cl(p[:, i]) for i, cl in enumerate(self.parts_identity_classifier)]
+            bn_p = torch.stack([o[0] for o in outs], 1)
+            s_p = torch.stack([o[1] for o in outs], 1)
+        emb = {GLOBAL: g, BACKGROUND: b, FOREGROUND: f, CONCAT_PARTS: c, PARTS: p,
+               BN_GLOBAL: bn_g, BN_BACKGROUND: bn_b, BN_FOREGROUND: bn_f, BN_CONCAT_PARTS: bn_c, BN_PARTS: bn_p}
+        visd = {GLOBAL: glob_vis, BACKGROUND: bg_vis, FOREGROUND: fg_vis, CONCAT_PARTS: fg_vis, PARTS: parts_vis}
+        ids = {GLOBAL: s_g, BACKGROUND: s_b, FOREGROUND: s_f, CONCAT_PARTS: s_c, PARTS: s_p}
+        masks = {GLOBAL: torch.ones_like(fg), BACKGROUND: bg, FOREGROUND: fg, CONCAT_PARTS: fg, PARTS: parts}
+        return emb, visd, ids, pix_scores, feats, masks

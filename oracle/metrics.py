@@ -1,0 +1,98 @@
+"""CPU restatement of the eval-time part-based distance and ranking (TEST INFRASTRUCTURE).
+
+Restates torchreid/metrics/distance.py:87-247 (three visibility modes, gallery batching,
+invalid -> max+1) and torchreid/metrics/rank.py:97-159 (market1501 protocol) / :16-94 (cuhk03).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def _part_dists(qf, gf, metric):
+    """distance.py:222-247: qf [Q,P,D], gf [G,P,D] -> [P,Q,G]."""
+    q, g = qf.transpose(0, 1), gf.transpose(0, 1)
+    dot = q @ g.transpose(1, 2)
+    if metric == 'cosine':
+        return 1 - dot
+    d = q.pow(2).sum(-1).unsqueeze(2) - 2 * dot + g.pow(2).sum(-1).unsqueeze(1)
+    return torch.sqrt(F.relu(d))
+
+
+def _masked_mean(x, mask):
+    w = mask.sum(0)
+    out = (x * mask).sum(0) / (w + (w == 0))
+    inv = mask.sum(0) == 0
+    return out * (~inv) + inv * (-1.0)
+
+
+def part_based_distance(qf, gf, qvis=None, gvis=None, strat='mean', batch=5000, metric='euclidean'):
+    """compute_distance_matrix_using_bp_features (distance.py:87-219) -> (distmat[Q,G], parts[P,Q,G])."""
+    mode = 'none'
+    if qvis is not None and gvis is not None:
+        mode = 'bool' if (qvis.dtype is torch.bool and gvis.dtype is torch.bool) else 'float'
+    dists, parts = [], []
+    gv_chunks = torch.split(gvis, batch) if mode != 'none' else [None] * len(torch.split(gf, batch))
+    for gchunk, gv in zip(torch.split(gf, batch), gv_chunks):
+        pd = _part_dists(qf, gchunk, metric)
+        if mode == 'none':
+            if strat == 'max':
+                d = pd.max(0)[0]
+            elif strat == 'mean':
+                d = pd.mean(0)
+            else:
+                raise ValueError(strat)
+        elif mode == 'bool':
+            mask = qvis.t().unsqueeze(2) * gv.t().unsqueeze(1)
+            valid = pd * mask + (~mask) * (-1.0)
+            if strat == 'max':
+                d = valid.max(0)[0]
+            elif strat == 'mean':
+                d = _masked_mean(pd, mask)
+            else:
+                raise ValueError(strat)
+            pd = valid
+        else:
+            mask = torch.sqrt(qvis.t().unsqueeze(2) * gv.t().unsqueeze(1))
+            d = _masked_mean(pd, mask)
+        dists.append(d)
+        parts.append(pd)
+    dist, part = torch.cat(dists, 1), torch.cat(parts, 2)
+    if mode != 'none':
+        mx = part.max() + 1                                   # distance.py:171 / :214
+        inv = dist == -1.0
+        dist = dist * (~inv) + inv * mx
+        if mode == 'bool':
+            pinv = part == -1
+            part = part * (~pinv) + pinv * mx
+    return dist, part
+
+
+def eval_market1501(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50, indices=None):
+    """rank.py:97-159.  `indices` lets a caller supply the argsort (tie-handling experiments)."""
+    nq, ng = distmat.shape
+    max_rank = min(max_rank, ng)
+    if indices is None:
+        indices = np.argsort(distmat, axis=1)
+    matches = (g_pids[indices] == q_pids[:, None]).astype(np.int32)
+    cmcs, aps = [], []
+    for i in range(nq):
+        order = indices[i]
+        keep = ~((g_pids[order] == q_pids[i]) & (g_camids[order] == q_camids[i]))
+        raw = matches[i][keep]
+        if not raw.any():
+            continue
+        c = raw.cumsum()
+        c[c > 1] = 1
+        cmcs.append(c[:max_rank])
+        cs = raw.cumsum() / (np.arange(raw.size) + 1.0)
+        aps.append((cs * raw).sum() / raw.sum())
+    assert cmcs, 'all query identities do not appear in gallery'
+    cmc = np.asarray(cmcs).astype(np.float32).sum(0) / len(cmcs)
+    return {'cmc': cmc, 'mAP': float(np.mean(aps))}
+
+
+def evaluate_rank(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50, eval_metric='default'):
+    """rank.py:173-214 (default protocol only; cuhk03 draws np.random and is not pinned)."""
+    if eval_metric != 'default':
+        raise ValueError(eval_metric)
+    return eval_market1501(distmat, q_pids, g_pids, q_camids, g_camids, max_rank)

@@ -1,0 +1,93 @@
+"""Helpers shared by the golden-vector generator and the tests (data + seeded fills only).
+
+Because a 40 M-parameter state dict cannot be committed, fixtures store *outputs* only; the
+weights are regenerated on both sides from the state-dict KEY NAMES with `fill_state_dict_`
+(an order-independent, key-seeded fill), and the inputs from the seeds below.
+"""
+import types
+import zlib
+
+import numpy as np
+import torch
+
+
+def ns(**kw):
+    return types.SimpleNamespace(**kw)
+
+
+def make_cfg(backbone='hrnet32', parts_num=5, dim_reduce_output=512, last_stride=1,
+             learnable_attention_enabled=True, shared_parts_id_classifier=False,
+             training_binary_visibility_score=True, testing_binary_visibility_score=True,
+             test_use_target_segmentation='none', test_embeddings=('bn_foreg', 'parts')):
+    """A duck-typed stand-in for the cfg.model.bpbreid subtree (default_config.py:43-68)."""
+    b = ns(pooling='gwap', normalization='identity', mask_filtering_training=False,
+           mask_filtering_testing=True, last_stride=last_stride, dim_reduce='after_pooling',
+           dim_reduce_output=dim_reduce_output, backbone=backbone,
+           learnable_attention_enabled=learnable_attention_enabled,
+           test_embeddings=list(test_embeddings),
+           test_use_target_segmentation=test_use_target_segmentation,
+           training_binary_visibility_score=training_binary_visibility_score,
+           testing_binary_visibility_score=testing_binary_visibility_score,
+           shared_parts_id_classifier=shared_parts_id_classifier, hrnet_pretrained_path='',
+           masks=ns(parts_num=parts_num))
+    return ns(model=ns(bpbreid=b, pretrained=False))
+
+
+def fill_state_dict_(module, seed=0):
+    """Deterministic, construction-order-independent fill of every parameter and buffer."""
+    with torch.no_grad():
+        for name, t in module.state_dict().items():
+            g = torch.Generator().manual_seed((zlib.crc32(name.encode()) ^ (seed * 2654435761)) & 0x7FFFFFFF)
+            leaf = name.rsplit('.', 1)[-1]
+            if leaf == 'num_batches_tracked':
+                t.zero_()
+            elif leaf == 'running_mean':
+                t.copy_(0.1 * torch.randn(t.shape, generator=g))
+            elif leaf == 'running_var':
+                t.copy_(1.0 + 0.2 * torch.rand(t.shape, generator=g))
+            elif t.dim() == 4:                       # conv weight: He fan-in
+                fan = t.shape[1] * t.shape[2] * t.shape[3]
+                t.copy_(torch.randn(t.shape, generator=g) * (2.0 / fan) ** 0.5)
+            elif t.dim() == 2:                       # linear weight
+                t.copy_(torch.randn(t.shape, generator=g) * (1.0 / t.shape[1]) ** 0.5)
+            elif leaf == 'weight':                   # BN gamma
+                t.copy_(1.0 + 0.1 * torch.randn(t.shape, generator=g))
+            else:                                    # any bias / BN beta
+                t.copy_(0.05 * torch.randn(t.shape, generator=g))
+    return module
+
+
+def synth_batch(n, h, w, k, num_classes, seed=1234, instances=4):
+    """SURVEY 8d synthetic batch: randn images, softmax(15*U) masks at H/4 x W/4, PxK pids."""
+    g = torch.Generator().manual_seed(seed)
+    imgs = torch.randn(n, 3, h, w, generator=g)
+    masks = torch.softmax(15 * torch.rand(n, k + 1, h // 4, w // 4, generator=g), dim=1)
+    ids = torch.randperm(num_classes, generator=g)[: max(1, n // instances)]
+    pids = ids.repeat_interleave(instances)[:n]
+    if pids.numel() < n:
+        pids = torch.cat([pids, ids[: n - pids.numel()]])
+    pids = pids[torch.randperm(n, generator=g)]
+    return imgs, masks, pids
+
+
+def subsample(t, stride=61):
+    """Fixed strided subsample of a big tensor (flattened) for compact fixtures."""
+    return t.detach().flatten()[::stride].clone()
+
+
+def grad_digest(named_params, nsample=8):
+    """Per-parameter gradient digest: [sum, abs-sum, first nsample strided elements]."""
+    out = {}
+    for name, p in named_params:
+        if p.grad is None:
+            continue
+        gflat = p.grad.detach().flatten().double()
+        step = max(1, gflat.numel() // nsample)
+        out[name] = torch.cat([gflat.sum()[None], gflat.abs().sum()[None], gflat[::step][:nsample]]).numpy()
+    return out
+
+
+def to_np(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu().numpy()
+    return np.asarray(x)

@@ -1,0 +1,350 @@
+"""Generate the golden vectors in tests/golden/*.npz by IMPORTING THE REAL REFERENCE.
+
+Runs only in the dev container (needs /root/reference); the produced .npz files are data
+(inputs are seed-regenerated, outputs stored) and are what travels to the GPU box.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py [model|loss|metric|traj ...]
+
+Reference entry points exercised (file:line under /root/reference/torchreid):
+  models/bpbreid.py:510 bpbreid() -> BPBreID.forward :116 ; models/hrnet.py:314 ; models/resnet.py:430
+  losses/GiLt_loss.py:11 ; losses/__init__.py:24 init_part_based_triplet_loss ;
+  losses/body_part_attention_loss.py:11 ; losses/hard_mine_triplet_loss.py:6
+  metrics/distance.py:87 ; metrics/rank.py:173 ; utils/tensortools.py:12
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _ref_loader as L          # noqa: E402
+import common as C               # noqa: E402
+
+warnings.filterwarnings('ignore')
+torch.set_num_threads(8)
+
+
+class NullWriter:
+    def __getattr__(self, name):
+        return lambda *a, **k: None
+
+
+def ref_cfg(backbone, k, d, **over):
+    cfg = L.default_cfg()
+    b = cfg.model.bpbreid
+    b.backbone = backbone
+    b.masks.parts_num = k
+    b.dim_reduce_output = d
+    for kk, v in over.items():
+        setattr(b, kk, v)
+    return cfg
+
+
+def register_hrnet_width(name, widths):
+    """W48 / narrow test widths = the reference class with NUM_CHANNELS overridden."""
+    from torchreid import models
+    from torchreid.models import hrnet
+
+    def ctor(num_classes, loss='part_based', pretrained=False, enable_dim_reduction=True,
+             dim_reduction_channels=256, **kw):
+        cfg = hrnet.get_hrnet_config()
+        for s, nb in (('STAGE2', 2), ('STAGE3', 3), ('STAGE4', 4)):
+            cfg.MODEL.EXTRA[s].NUM_CHANNELS = list(widths[:nb])
+        return hrnet.HighResolutionNet(cfg, enable_dim_reduction, dim_reduction_channels)
+    models.__dict__['__model_factory'][name] = ctor
+
+
+WEIGHTS_MARKET = {'globl': {'id': 1., 'tr': 0.}, 'foreg': {'id': 1., 'tr': 1.},
+                  'conct': {'id': 1., 'tr': 0.}, 'parts': {'id': 0., 'tr': 1.}, 'pixls': {'ce': 0.35}}
+WEIGHTS_DEFAULT = {'globl': {'id': 1., 'tr': 0.}, 'foreg': {'id': 1., 'tr': 0.},
+                   'conct': {'id': 1., 'tr': 0.}, 'parts': {'id': 0., 'tr': 1.}, 'pixls': {'ce': 0.35}}
+
+
+def ref_combined_loss(out, pids, masks, weights, use_vis):
+    """GiLt + BPA exactly as ImagePartBasedEngine.combine_losses does (part_based_engine.py:107-130)."""
+    from torchreid.losses.GiLt_loss import GiLtLoss
+    from torchreid.losses.body_part_attention_loss import BodyPartAttentionLoss
+    emb, vis, ids, pix, _, _ = out
+    gilt = GiLtLoss(weights, use_visibility_scores=use_vis, triplet_margin=0.3,
+                    loss_name='part_averaged_triplet_loss', writer=NullWriter(), use_gpu=False)
+    loss, summ = gilt(emb, vis, ids, pids)
+    tm = torch.nn.functional.interpolate(masks.to(pix.dtype), pix.shape[2:], mode='bilinear', align_corners=True)
+    bpa, _ = BodyPartAttentionLoss(loss_type='cl', use_gpu=False)(pix, tm.argmax(dim=1))
+    return loss + weights['pixls']['ce'] * bpa, summ, bpa
+
+
+def dump_outputs(store, prefix, out):
+    emb, vis, ids, pix, sp, mk = out
+    for k, v in emb.items():
+        store['%s/emb/%s' % (prefix, k)] = C.to_np(v)
+    for k, v in vis.items():
+        store['%s/vis/%s' % (prefix, k)] = C.to_np(v)
+    for k, v in ids.items():
+        store['%s/ids/%s' % (prefix, k)] = C.to_np(v)
+    store['%s/pix' % prefix] = C.to_np(pix)
+    store['%s/sp_sub' % prefix] = C.to_np(C.subsample(sp))
+    store['%s/sp_chan_mean' % prefix] = C.to_np(sp.mean(dim=(0, 2, 3)))
+    store['%s/mask_parts' % prefix] = C.to_np(mk['parts'])
+    store['%s/mask_foreg' % prefix] = C.to_np(mk['foreg'])
+
+
+MODEL_CASES = {
+    # name: (backbone, K, D, N, H, W, classes, extra cfg)
+    'hrw8_k5': ('hrnet_w8', 5, 64, 8, 64, 32, 16, {}),
+    'hrw8_k5_float_vis': ('hrnet_w8', 5, 64, 8, 64, 32, 16,
+                          {'training_binary_visibility_score': False, 'testing_binary_visibility_score': False}),
+    'hrw8_k3_shared': ('hrnet_w8', 3, 64, 8, 64, 32, 16, {'shared_parts_id_classifier': True}),
+    'hr32_k5': ('hrnet32', 5, 512, 8, 128, 64, 16, {}),
+    'hr32_k5_full': ('hrnet32', 5, 512, 4, 256, 128, 751, {}),
+    'r50_k2': ('resnet50', 2, 512, 8, 128, 64, 16, {}),
+    'r50_k5_full': ('resnet50', 5, 512, 8, 256, 128, 751, {}),
+    'hr48_k8': ('hrnet48', 8, 512, 4, 192, 64, 16, {}),
+}
+
+
+def gen_model(name):
+    from torchreid import models
+    backbone, k, d, n, h, w, ncls, extra = MODEL_CASES[name]
+    imgs, masks, pids = C.synth_batch(n, h, w, k, ncls)
+    store = {'meta': np.array([k, d, n, h, w, ncls])}
+    for dt, tag in ((torch.float32, 'f32'), (torch.float64, 'f64')):
+        torch.manual_seed(0)
+        model = models.build_model('bpbreid', num_classes=ncls, loss='part_based', pretrained=False,
+                                   config=ref_cfg(backbone, k, d, **extra))
+        C.fill_state_dict_(model)
+        model = model.to(dt)
+        model.train()
+        out = model(imgs.to(dt), external_parts_masks=masks.to(dt))
+        dump_outputs(store, tag + '/train', out)
+        float_vis = extra.get('training_binary_visibility_score', True) is False
+        # The reference's triplet loss cannot run in fp64 ((~mask).float()*finfo(f64).max overflows to inf,
+        # part_averaged_triplet_loss.py:145): the fp64 arbiter evaluates the LOSS in fp32 on the fp64 model
+        # outputs (autograd carries the cast), which keeps the deep part (the model) in fp64.
+        f32 = lambda dct: {kk: (v.float() if v.is_floating_point() else v) for kk, v in dct.items()}
+        out_l = (f32(out[0]), f32(out[1]), f32(out[2]), out[3].float(), out[4], out[5])
+        mask_l = masks
+        loss, summ, bpa = ref_combined_loss(out_l, pids, mask_l, WEIGHTS_MARKET, use_vis=True)
+        store[tag + '/loss_market_vis'] = C.to_np(loss)
+        store[tag + '/loss_bpa'] = C.to_np(bpa)
+        for kk, info in summ.items():
+            for nm, v in info.items():
+                store['%s/summ/%s/%s' % (tag, kk, nm)] = C.to_np(torch.as_tensor(v))
+        model.zero_grad()
+        loss.backward()
+        for pn, dg in C.grad_digest(model.named_parameters()).items():
+            store['%s/grad/%s' % (tag, pn)] = dg
+        if not float_vis:
+            loss2, _, _ = ref_combined_loss(out_l, pids, mask_l, WEIGHTS_DEFAULT, use_vis=False)
+            store[tag + '/loss_default_novis'] = C.to_np(loss2)
+        sd = model.state_dict()
+        rs = [kk for kk in sd if kk.endswith('running_mean') or kk.endswith('running_var')]
+        store[tag + '/running_digest'] = np.array([float(sd[kk].double().sum()) for kk in rs])
+        store[tag + '/bn1_running_mean'] = C.to_np(sd['backbone_appearance_feature_extractor.bn1.running_mean'])
+        store[tag + '/pixbn_running_var'] = C.to_np(sd['pixel_classifier.bn.running_var'])
+        model.eval()
+        with torch.no_grad():
+            out = model(imgs.to(dt), external_parts_masks=masks.to(dt))
+        dump_outputs(store, tag + '/eval', out)
+    np.savez_compressed(os.path.join(HERE, 'model_%s.npz' % name), **store)
+    print('model', name, 'ok  loss', float(store['f32/loss_market_vis']))
+
+
+TRIPLET_NAMES = ['part_averaged_triplet_loss', 'part_max_triplet_loss', 'part_min_triplet_loss',
+                 'part_max_min_triplet_loss', 'intra_parts_triplet_loss', 'part_random_max_min_triplet_loss']
+
+
+def gen_loss():
+    from torchreid.losses import init_part_based_triplet_loss, CrossEntropyLoss, TripletLoss
+    from torchreid.losses.GiLt_loss import GiLtLoss
+    from torchreid.utils.tensortools import masked_mean
+    g = torch.Generator().manual_seed(7)
+    n, k, d, ncls = 16, 5, 32, 10
+    emb = torch.randn(n, k, d, generator=g)
+    pids = torch.arange(4).repeat_interleave(4)[torch.randperm(n, generator=g)]
+    vis_bool = torch.rand(n, k, generator=g) > 0.3
+    vis_bool[3] = False                      # a fully invisible sample
+    vis_bool[5] = torch.tensor([True, False, False, False, False])
+    vis_bool[6] = torch.tensor([False, True, False, False, False])   # 5 and 6 share no visible part
+    vis_float = torch.rand(n, k, generator=g)
+    vis_float[2] = 0.0
+    # an identity with a single member -> that anchor has no valid positive
+    pids_single = pids.clone()
+    pids_single[0] = 9
+    store = {'emb': emb.numpy(), 'pids': pids.numpy(), 'vis_bool': vis_bool.numpy(),
+             'vis_float': vis_float.numpy(), 'pids_single': pids_single.numpy()}
+    for name in TRIPLET_NAMES:
+        for vname, vis in (('none', None), ('bool', vis_bool), ('float', vis_float)):
+            if vname == 'float' and name != 'part_averaged_triplet_loss':
+                continue                     # reference raises TypeError (~ on float), SURVEY 2.1 #7
+            for pname, pp in (('pids', pids), ('pids_single', pids_single)):
+                for margin in (0.3, 0.0):
+                    e = emb.clone().requires_grad_(True)
+                    torch.manual_seed(123)   # part_random_max_min draws torch.rand
+                    lossf = init_part_based_triplet_loss(name, margin=margin, writer=NullWriter())
+                    res = lossf(e, pp, parts_visibility=vis)
+                    key = 'tri/%s/%s/%s/m%g' % (name, vname, pname, margin)
+                    store[key + '/vals'] = np.array([float(x) for x in res])
+                    res[0].backward()
+                    store[key + '/grad'] = e.grad.numpy()
+    # K=1 no-visibility == classic batch-hard triplet (docstring claim, part_averaged_triplet_loss.py:16-19)
+    e1 = torch.randn(32, 64, generator=g)
+    p1 = torch.arange(8).repeat_interleave(4)
+    store['kat/emb'] = e1.numpy()
+    store['kat/pids'] = p1.numpy()
+    store['kat/classic'] = np.array(float(TripletLoss(margin=0.3)(e1, p1)))
+    store['kat/part'] = np.array(float(init_part_based_triplet_loss(
+        'part_averaged_triplet_loss', margin=0.3, writer=NullWriter())(e1.unsqueeze(1), p1)[0]))
+    # label-smoothed CE, unweighted and weighted
+    logits = torch.randn(n, ncls, generator=g)
+    tgt = torch.randint(0, ncls, (n,), generator=g)
+    w = torch.rand(n, generator=g)
+    ce = CrossEntropyLoss(label_smooth=True)
+    for nm, ww in (('plain', None), ('weighted', w)):
+        lg = logits.clone().requires_grad_(True)
+        v = ce(lg, tgt, ww)
+        v.backward()
+        store['ce/%s/val' % nm] = np.array(float(v))
+        store['ce/%s/grad' % nm] = lg.grad.numpy()
+    store['ce/logits'], store['ce/targets'], store['ce/weights'] = logits.numpy(), tgt.numpy(), w.numpy()
+    # masked_mean semantics
+    x = torch.rand(k, n, n, generator=g)
+    mb = torch.rand(k, n, n, generator=g) > 0.5
+    mb[:, 0, 1] = False
+    store['mm/x'], store['mm/mask'] = x.numpy(), mb.numpy()
+    store['mm/out'] = masked_mean(x, mb).numpy()
+    # GiLt over dict inputs, three visibility modes
+    D = 24
+    embd = {'globl': torch.randn(n, D, generator=g), 'foreg': torch.randn(n, D, generator=g),
+            'conct': torch.randn(n, k * D, generator=g), 'parts': torch.randn(n, k, D, generator=g)}
+    ids = {'globl': torch.randn(n, ncls, generator=g), 'foreg': torch.randn(n, ncls, generator=g),
+           'conct': torch.randn(n, ncls, generator=g), 'parts': torch.randn(n, k, ncls, generator=g)}
+    for kk, v in embd.items():
+        store['gilt/emb/' + kk] = v.numpy()
+    for kk, v in ids.items():
+        store['gilt/ids/' + kk] = v.numpy()
+    pidc = pids % ncls
+    wts = {'globl': {'id': 1., 'tr': 0.5}, 'foreg': {'id': 1., 'tr': 1.}, 'conct': {'id': 1., 'tr': 0.},
+           'parts': {'id': 0.7, 'tr': 1.}}
+    for vname in ('none', 'bool', 'float'):
+        if vname == 'float':
+            pv = vis_float
+            visd = {'globl': torch.ones(n), 'foreg': pv.amax(1), 'conct': pv.amax(1), 'parts': pv}
+        else:
+            pv = vis_bool
+            visd = {'globl': torch.ones(n, dtype=torch.bool), 'foreg': pv.amax(1), 'conct': pv.amax(1), 'parts': pv}
+        gl = GiLtLoss(wts, use_visibility_scores=(vname != 'none'), triplet_margin=0.3,
+                      loss_name='part_averaged_triplet_loss', writer=NullWriter(), use_gpu=False)
+        leaves = {kk: v.clone().requires_grad_(True) for kk, v in embd.items()}
+        lids = {kk: v.clone().requires_grad_(True) for kk, v in ids.items()}
+        loss, summ = gl(leaves, visd, lids, pidc)
+        loss.backward()
+        store['gilt/%s/loss' % vname] = np.array(float(loss))
+        for kk in leaves:
+            if leaves[kk].grad is not None:
+                store['gilt/%s/gemb/%s' % (vname, kk)] = leaves[kk].grad.numpy()
+            if lids[kk].grad is not None:
+                store['gilt/%s/gids/%s' % (vname, kk)] = lids[kk].grad.numpy()
+        for kk, info in summ.items():
+            for nm, v in info.items():
+                store['gilt/%s/summ/%s/%s' % (vname, kk, nm)] = np.array(float(v))
+    np.savez_compressed(os.path.join(HERE, 'losses.npz'), **store)
+    print('loss ok', len(store), 'arrays')
+
+
+def gen_metric():
+    from torchreid.metrics.distance import compute_distance_matrix_using_bp_features
+    from torchreid.metrics.rank import evaluate_rank
+    g = torch.Generator().manual_seed(4321)
+    q, G, p, d = 12, 30, 6, 16
+    qf = torch.nn.functional.normalize(torch.randn(q, p, d, generator=g), dim=-1)
+    gf = torch.nn.functional.normalize(torch.randn(G, p, d, generator=g), dim=-1)
+    qv = torch.rand(q, p, generator=g) < 0.8
+    gv = torch.rand(G, p, generator=g) < 0.8
+    qv[:, 0] = True
+    gv[:, 0] = True
+    qv[2] = torch.tensor([False, True, False, False, False, False])
+    gv[4] = torch.tensor([False, False, True, False, False, False])     # (2,4) share no visible part
+    qvf, gvf = torch.rand(q, p, generator=g), torch.rand(G, p, generator=g)
+    qvf[1], gvf[3] = 0.0, 0.0
+    store = {'qf': qf.numpy(), 'gf': gf.numpy(), 'qv': qv.numpy(), 'gv': gv.numpy(),
+             'qvf': qvf.numpy(), 'gvf': gvf.numpy()}
+    for vname, a, b in (('none', None, None), ('bool', qv, gv), ('float', qvf, gvf)):
+        for strat in ('mean', 'max'):
+            for metric in ('euclidean', 'cosine'):
+                for batch in (7, 5000):
+                    dm, pm = compute_distance_matrix_using_bp_features(qf, gf, a, b, strat, batch, False, metric)
+                    key = 'dist/%s/%s/%s/b%d' % (vname, strat, metric, batch)
+                    store[key + '/distmat'] = dm.numpy()
+                    store[key + '/parts'] = pm.numpy()
+    # ranking: the shape used by the reference's own timing script (rank_cylib/test_cython.py:22-36)
+    rs = np.random.RandomState(0)
+    nq, ng = 30, 300
+    distmat = rs.rand(nq, ng).astype(np.float32) * 20
+    q_pids = rs.randint(0, 10, nq)
+    g_pids = rs.randint(0, 10, ng)
+    q_cam = rs.randint(0, 5, nq)
+    g_cam = rs.randint(0, 5, ng)
+    res = evaluate_rank(distmat, q_pids, g_pids, q_cam, g_cam, max_rank=50, eval_metric='default')
+    store.update({'rank/distmat': distmat, 'rank/q_pids': q_pids, 'rank/g_pids': g_pids, 'rank/q_cam': q_cam,
+                  'rank/g_cam': g_cam, 'rank/cmc': res['cmc'], 'rank/mAP': np.array(res['mAP']),
+                  'rank/indices': np.argsort(distmat, axis=1)})
+    # a query whose identity is absent from the gallery (skipped, rank.py:131-133).  NB: a gallery smaller
+    # than max_rank makes the reference itself crash (ragged cmc rows, rank.py:152), so it is not a vector.
+    q_pids2 = q_pids.copy()
+    q_pids2[0] = 99
+    res2 = evaluate_rank(distmat, q_pids2, g_pids, q_cam, g_cam, max_rank=50)
+    store.update({'rank2/q_pids': q_pids2, 'rank2/cmc': res2['cmc'], 'rank2/mAP': np.array(res2['mAP'])})
+    np.savez_compressed(os.path.join(HERE, 'metrics.npz'), **store)
+    print('metric ok')
+
+
+def gen_traj():
+    """Two full optimisation steps of config 1 (ResNet-50 K=2 N=16 256x128): loss trajectory."""
+    from torchreid import models
+    k, d, n, h, w, ncls = 2, 512, 16, 256, 128, 751
+    torch.manual_seed(0)
+    model = models.build_model('bpbreid', num_classes=ncls, loss='part_based', pretrained=False,
+                               config=ref_cfg('resnet50', k, d))
+    C.fill_state_dict_(model)
+    model.train()
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=3.5e-4,
+                           weight_decay=5e-4, betas=(0.9, 0.999))
+    store = {}
+    losses = []
+    for step in range(2):
+        imgs, masks, pids = C.synth_batch(n, h, w, k, ncls, seed=1234 + step)
+        out = model(imgs, external_parts_masks=masks)
+        loss, _, _ = ref_combined_loss(out, pids, masks, WEIGHTS_DEFAULT, use_vis=False)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    sd = model.state_dict()
+    store['losses'] = np.array(losses)
+    store['conv1_w_sub'] = C.to_np(C.subsample(sd['backbone_appearance_feature_extractor.conv1.weight'], 97))
+    store['pixcls_w'] = C.to_np(sd['pixel_classifier.classifier.weight']).reshape(k + 1, -1)[:, ::64]
+    store['gid_cls_sub'] = C.to_np(C.subsample(sd['global_identity_classifier.classifier.weight'], 997))
+    np.savez_compressed(os.path.join(HERE, 'traj_r50_k2.npz'), **store)
+    print('traj ok', losses)
+
+
+if __name__ == '__main__':
+    L.load_reference()
+    register_hrnet_width('hrnet48', (48, 96, 192, 384))
+    register_hrnet_width('hrnet_w8', (8, 16, 32, 64))
+    what = sys.argv[1:] or ['loss', 'metric', 'model', 'traj']
+    if 'loss' in what:
+        gen_loss()
+    if 'metric' in what:
+        gen_metric()
+    if 'model' in what:
+        for nm in MODEL_CASES:
+            gen_model(nm)
+    if 'traj' in what:
+        gen_traj()
+    for m in what:
+        if m in MODEL_CASES:
+            gen_model(m)

@@ -1,0 +1,182 @@
+"""Pin the CPU oracle (oracle/) against golden vectors produced by the real reference.
+
+Tolerances: relative to the tensor's scale, and bounded by the reference's own fp32-vs-fp64
+noise: |oracle32 - ref64| <= c * max(|ref32 - ref64|, 1e-6*scale).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import common as C
+from oracle import losses as OL
+from oracle import metrics as OM
+from oracle.bpbreid import BPBreID
+
+torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+
+MODEL_CASES = {
+    'hrw8_k5': ('hrnet_w8', {}),
+    'hrw8_k5_float_vis': ('hrnet_w8', {'training_binary_visibility_score': False,
+                                       'testing_binary_visibility_score': False}),
+    'hrw8_k3_shared': ('hrnet_w8', {'shared_parts_id_classifier': True}),
+    'hr32_k5': ('hrnet32', {}),
+    'r50_k2': ('resnet50', {}),
+    'hr48_k8': ('hrnet48', {}),
+}
+WEIGHTS_MARKET = {'globl': {'id': 1., 'tr': 0.}, 'foreg': {'id': 1., 'tr': 1.},
+                  'conct': {'id': 1., 'tr': 0.}, 'parts': {'id': 0., 'tr': 1.}}
+
+
+def close(got, ref32, ref64, c=6.0, rel=2e-4):
+    got, ref32, ref64 = [np.asarray(a, dtype=np.float64) for a in (got, ref32, ref64)]
+    scale = max(np.abs(ref64).max(), 1e-12)
+    noise = np.abs(ref32 - ref64).max()
+    err = np.abs(got - ref64).max()
+    assert err <= max(c * noise, rel * scale), (err, noise, scale)
+
+
+def check_outputs(z, tag32, tag64, out):
+    emb, vis, ids, pix, sp, mk = out
+    for k, v in emb.items():
+        close(C.to_np(v), z['%s/emb/%s' % (tag32, k)], z['%s/emb/%s' % (tag64, k)])
+    for k, v in ids.items():
+        close(C.to_np(v), z['%s/ids/%s' % (tag32, k)], z['%s/ids/%s' % (tag64, k)])
+    for k, v in vis.items():
+        ref = z['%s/vis/%s' % (tag32, k)]
+        if ref.dtype == np.bool_:
+            assert v.dtype is torch.bool and np.array_equal(C.to_np(v), ref), k
+        else:
+            close(C.to_np(v), ref, z['%s/vis/%s' % (tag64, k)])
+    close(C.to_np(pix), z[tag32 + '/pix'], z[tag64 + '/pix'])
+    close(C.to_np(C.subsample(sp)), z[tag32 + '/sp_sub'], z[tag64 + '/sp_sub'])
+    close(C.to_np(mk['parts']), z[tag32 + '/mask_parts'], z[tag64 + '/mask_parts'])
+
+
+@pytest.mark.parametrize('name', list(MODEL_CASES))
+def test_model_forward_loss_grads(name, golden_dir):
+    path = os.path.join(golden_dir, 'model_%s.npz' % name)
+    if not os.path.exists(path):
+        pytest.skip('fixture not generated')
+    z = np.load(path)
+    backbone, extra = MODEL_CASES[name]
+    k, d, n, h, w, ncls = [int(x) for x in z['meta']]
+    cfg = C.make_cfg(backbone, k, d, **extra)
+    model = C.fill_state_dict_(BPBreID(ncls, cfg))
+    imgs, masks, pids = C.synth_batch(n, h, w, k, ncls)
+    model.train()
+    out = model(imgs, masks)
+    check_outputs(z, 'f32/train', 'f64/train', out)
+    loss, summ = OL.combined_loss(out, pids, masks, WEIGHTS_MARKET, 0.35, use_visibility=True)
+    close(float(loss.detach()), z['f32/loss_market_vis'], z['f64/loss_market_vis'])
+    close(float(summ['pixls']['c']), z['f32/loss_bpa'], z['f64/loss_bpa'])
+    for kk, info in summ.items():
+        for nm, v in info.items():
+            if kk != 'pixls':
+                close(float(v), z['f32/summ/%s/%s' % (kk, nm)], z['f64/summ/%s/%s' % (kk, nm)], rel=1e-3)
+    loss.backward()
+    digests = C.grad_digest(model.named_parameters())
+    ref_names = [kk[len('f32/grad/'):] for kk in z.files if kk.startswith('f32/grad/')]
+    assert sorted(digests) == sorted(ref_names)          # same set of parameters receive gradients
+    for pn, dg in digests.items():
+        r32, r64 = z['f32/grad/' + pn], z['f64/grad/' + pn]
+        scale = max(np.abs(r64[2:]).max(), np.abs(r64[1]) / max(1, r64.size), 1e-9)
+        noise = np.abs(r32[2:] - r64[2:]).max()
+        assert np.abs(dg[2:] - r64[2:]).max() <= max(8 * noise, 2e-3 * scale), pn
+    sd = model.state_dict()
+    rs = [kk for kk in sd if kk.endswith('running_mean') or kk.endswith('running_var')]
+    got = np.array([float(sd[kk].double().sum()) for kk in rs])
+    assert np.allclose(got, z['f64/running_digest'], rtol=1e-4, atol=1e-4)
+    model.eval()
+    with torch.no_grad():
+        out = model(imgs, masks)
+    check_outputs(z, 'f32/eval', 'f64/eval', out)
+
+
+def test_triplet_family(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'losses.npz'))
+    emb = torch.from_numpy(z['emb'])
+    vis = {'none': None, 'bool': torch.from_numpy(z['vis_bool']), 'float': torch.from_numpy(z['vis_float'])}
+    keys = [k for k in z.files if k.startswith('tri/') and k.endswith('/vals')]
+    assert len(keys) >= 40
+    for key in keys:
+        _, name, vname, pname, m, _ = key.split('/')
+        e = emb.clone().requires_grad_(True)
+        torch.manual_seed(123)
+        res = OL.part_triplet(name, e, torch.from_numpy(z[pname]), vis[vname], float(m[1:]))
+        assert np.allclose([float(x) for x in res], z[key], rtol=1e-5, atol=1e-6), key
+        res[0].backward()
+        assert np.allclose(e.grad.numpy(), z[key[:-5] + '/grad'], rtol=1e-4, atol=1e-6), key
+
+
+def test_known_answer_k1_equals_classic_triplet(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'losses.npz'))
+    e, p = torch.from_numpy(z['kat/emb']), torch.from_numpy(z['kat/pids'])
+    v = OL.part_triplet('part_averaged_triplet_loss', e.unsqueeze(1), p, None, 0.3)[0]
+    assert abs(float(v) - float(z['kat/part'])) < 1e-6
+    assert abs(float(v) - float(z['kat/classic'])) < 1e-5     # differs only by clamp(1e-12) vs epsilon trick
+
+
+def test_ce_and_masked_mean(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'losses.npz'))
+    logits, tgt, w = [torch.from_numpy(z['ce/' + k]) for k in ('logits', 'targets', 'weights')]
+    for nm, ww in (('plain', None), ('weighted', w)):
+        lg = logits.clone().requires_grad_(True)
+        v = OL.label_smooth_ce(lg, tgt, ww)
+        v.backward()
+        assert abs(float(v) - float(z['ce/%s/val' % nm])) < 1e-6
+        assert np.allclose(lg.grad.numpy(), z['ce/%s/grad' % nm], atol=1e-7)
+    mm = OL.masked_mean(torch.from_numpy(z['mm/x']), torch.from_numpy(z['mm/mask']))
+    assert np.allclose(mm.numpy(), z['mm/out'], atol=1e-7)
+    assert float(mm[0, 1]) == -1.0
+
+
+def test_gilt_three_visibility_modes(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'losses.npz'))
+    n, k = z['emb'].shape[:2]
+    ncls = z['ce/logits'].shape[1]
+    pids = torch.from_numpy(z['pids']) % ncls
+    wts = {'globl': {'id': 1., 'tr': 0.5}, 'foreg': {'id': 1., 'tr': 1.}, 'conct': {'id': 1., 'tr': 0.},
+           'parts': {'id': 0.7, 'tr': 1.}}
+    for vname in ('none', 'bool', 'float'):
+        pv = torch.from_numpy(z['vis_float'] if vname == 'float' else z['vis_bool'])
+        one = torch.ones(n) if vname == 'float' else torch.ones(n, dtype=torch.bool)
+        visd = {'globl': one, 'foreg': pv.amax(1), 'conct': pv.amax(1), 'parts': pv}
+        emb = {kk: torch.from_numpy(z['gilt/emb/' + kk]).requires_grad_(True) for kk in wts}
+        ids = {kk: torch.from_numpy(z['gilt/ids/' + kk]).requires_grad_(True) for kk in wts}
+        loss, summ = OL.gilt(emb, visd, ids, pids, wts, use_visibility=(vname != 'none'))
+        assert abs(float(loss) - float(z['gilt/%s/loss' % vname])) < 2e-5
+        loss.backward()
+        for kk in wts:
+            for nm, t in (('gemb', emb[kk]), ('gids', ids[kk])):
+                key = 'gilt/%s/%s/%s' % (vname, nm, kk)
+                if key in z.files:
+                    assert np.allclose(t.grad.numpy(), z[key], rtol=1e-4, atol=1e-6), key
+        for kk, info in summ.items():
+            for nm, v in info.items():
+                assert abs(float(v) - float(z['gilt/%s/summ/%s/%s' % (vname, kk, nm)])) < 2e-5
+
+
+def test_distance_all_modes(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'metrics.npz'))
+    qf, gf = torch.from_numpy(z['qf']), torch.from_numpy(z['gf'])
+    vis = {'none': (None, None), 'bool': (torch.from_numpy(z['qv']), torch.from_numpy(z['gv'])),
+           'float': (torch.from_numpy(z['qvf']), torch.from_numpy(z['gvf']))}
+    keys = [k for k in z.files if k.startswith('dist/') and k.endswith('/distmat')]
+    assert len(keys) == 24
+    for key in keys:
+        _, vname, strat, metric, b, _ = key.split('/')
+        dm, pm = OM.part_based_distance(qf, gf, vis[vname][0], vis[vname][1], strat, int(b[1:]), metric)
+        assert np.allclose(dm.numpy(), z[key], atol=1e-6), key
+        assert np.allclose(pm.numpy(), z[key[:-8] + '/parts'], atol=1e-6), key
+
+
+def test_rank_market1501(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'metrics.npz'))
+    res = OM.evaluate_rank(z['rank/distmat'], z['rank/q_pids'], z['rank/g_pids'], z['rank/q_cam'], z['rank/g_cam'])
+    assert np.array_equal(res['cmc'], z['rank/cmc'])
+    assert res['mAP'] == float(z['rank/mAP'])
+    assert np.array_equal(np.argsort(z['rank/distmat'], axis=1), z['rank/indices'])
+    res2 = OM.evaluate_rank(z['rank/distmat'], z['rank2/q_pids'], z['rank/g_pids'], z['rank/q_cam'], z['rank/g_cam'])
+    assert np.array_equal(res2['cmc'], z['rank2/cmc']) and res2['mAP'] == float(z['rank2/mAP'])
