@@ -1,0 +1,53 @@
+"""Build libbpbreid_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libbpbreid_hip.so')
+SOURCES = ['conv_igemm.hip', 'bn_act.hip', 'resample.hip', 'attn_pool.hip', 'dense.hip', 'losses.hip', 'optim.hip',
+           'distance.hip', 'rank.cpp', 'plan.cpp', 'bpb_common.cpp']
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, 'bpb_common.h')]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=True):
+    """Compile every HIP/C++ source into one shared library.  Objects are built in parallel."""
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objdir = os.path.join(HERE, 'build')
+    os.makedirs(objdir, exist_ok=True)
+    procs = []
+    objs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        if not os.path.exists(src):
+            continue
+        obj = os.path.join(objdir, s.rsplit('.', 1)[0] + '.o')
+        objs.append(obj)
+        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-x', 'hip', '-c', src, '-o', obj,
+               '-I', CSRC, '-Wno-unused-value']
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s, p in procs:
+        out = p.communicate()[0].decode()
+        if p.returncode != 0:
+            raise RuntimeError('hipcc failed on %s:\n%s' % (s, out))
+        if verbose and out.strip():
+            print(out)
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError('link failed:\n' + r.stdout.decode())
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='-f' in sys.argv))

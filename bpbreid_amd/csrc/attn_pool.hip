@@ -1,0 +1,599 @@
+// Body-part attention head: pixel->part classifier, softmax attention, visibility scores and
+// mask-weighted pooling, forward and backward (HBM-bound; fp32; NHWC feature map read with 16-byte
+// lanes, one wave = 256 consecutive channels of one pixel).
+//
+// Replaces torchreid/models/bpbreid.py:147-148 (BN2d -> 1x1 conv -> softmax), :157-158,178 (bg / parts /
+// fg = max over parts), :182-192 (visibility), :195-202 + :458-468,490-503 (global average pool, fg/bg
+// GAP heads, parts GWAP head).  The reference materialises masks[N,K,1,H,W] * feats[N,1,C,H,W]
+// (5 GB at N=64, K=5, HRNet-W32 -- its largest single cost); algebraically it is
+// [K+3, HW] x [HW, C] per image, which is what bpb_masked_pool computes without the temporary.
+//
+// Two generic streaming kernels carry all the heavy traffic (forward and backward):
+//   bpb_pixel_dots   out[n][p][j]   = sum_c w[n?][j][c] * x[n][p][c] (+ b[j])      (J <= 12 rows)
+//   bpb_masked_pool  part[n][q][j][c] = sum_{p in chunk q} m[n][j][p] * x[n][p][c]  (J <= 12 masks)
+#include "bpb_common.h"
+
+#define BPB_HEAD_MAXJ 12
+
+// ---------------------------------------------------------------------------------------------
+template <int J>
+__global__ __launch_bounds__(256) void bpb_pixel_dots_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             long w_image_stride, const float* __restrict__ bias,
+                                                             float* __restrict__ out, int HW, int C, int pix_per_block)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // w rows [J][C]
+    const int n = blockIdx.y;
+    const float* wn = w + (long)n * w_image_stride;
+    for (int i = threadIdx.x; i < J * (C >> 2); i += 256) *(f32x4*)(smem + i * 4) = *(const f32x4*)(wn + i * 4);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c4 = C >> 2;
+    const int p_begin = blockIdx.x * pix_per_block, p_end = min(HW, p_begin + pix_per_block);
+    constexpr int PB = 4;
+    for (int p0 = p_begin + wave * PB; p0 < p_end; p0 += 4 * PB) {
+        float acc[PB][J];
+#pragma unroll
+        for (int b = 0; b < PB; ++b)
+#pragma unroll
+            for (int j = 0; j < J; ++j) acc[b][j] = 0.f;
+        for (int cq = lane; cq < c4; cq += 64) {
+            f32x4 xv[PB];
+#pragma unroll
+            for (int b = 0; b < PB; ++b) {
+                const int p = min(p0 + b, p_end - 1);
+                xv[b] = *(const f32x4*)(x + ((long)n * HW + p) * C + cq * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const f32x4 wv = *(const f32x4*)(smem + j * C + cq * 4);
+#pragma unroll
+                for (int b = 0; b < PB; ++b)
+                    acc[b][j] += xv[b][0] * wv[0] + xv[b][1] * wv[1] + xv[b][2] * wv[2] + xv[b][3] * wv[3];
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < PB; ++b)
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                float v = acc[b][j];
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+                acc[b][j] = v;
+            }
+        if (lane < PB * J) {
+            const int b = lane / J, j = lane - b * J;
+            float v = 0.f;
+#pragma unroll
+            for (int bb = 0; bb < PB; ++bb)
+#pragma unroll
+                for (int jj = 0; jj < J; ++jj)
+                    if (bb == b && jj == j) v = acc[bb][jj];
+            if (p0 + b < p_end) out[((long)n * HW + p0 + b) * J + j] = v + (bias ? bias[j] : 0.f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// part[n][chunk][j][c] = sum_{p in chunk} m[n][j][p] * x[n][p][c];  m is [N][J][HW] (pixel-contiguous rows)
+template <int J>
+__global__ __launch_bounds__(256) void bpb_masked_pool_kernel(const float* __restrict__ x, const float* __restrict__ m,
+                                                              float* __restrict__ part, int HW, int C, int pix_per_block)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // masks of the chunk [J][pix_per_block]
+    const int n = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+    const int p_begin = chunk * pix_per_block, p_end = min(HW, p_begin + pix_per_block);
+    const int np = p_end - p_begin;
+    for (int i = threadIdx.x; i < J * pix_per_block; i += 256) {
+        const int j = i / pix_per_block, pp = i - j * pix_per_block;
+        smem[i] = pp < np ? m[((long)n * J + j) * HW + p_begin + pp] : 0.f;
+    }
+    __syncthreads();
+    const int c4 = C >> 2;
+    for (int cq = threadIdx.x; cq < c4; cq += 256) {
+        f32x4 acc[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* xp = x + ((long)n * HW + p_begin) * C + cq * 4;
+#pragma unroll 4
+        for (int pp = 0; pp < np; ++pp) {
+            const f32x4 xv = *(const f32x4*)(xp + (long)pp * C);
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const float mv = smem[j * pix_per_block + pp];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[j][e] += mv * xv[e];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) *(f32x4*)(part + (((long)n * nchunks + chunk) * J + j) * C + cq * 4) = acc[j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fold the pixel-classifier BatchNorm into the 1x1 conv:  w'[k][c] = w[k][c]*scale[c],
+// b'[k] = b[k] + sum_c w[k][c]*shift[c]   (bpbreid.py:383-385)
+__global__ __launch_bounds__(256) void bpb_fold_bn_kernel(const float* __restrict__ w, const float* __restrict__ b,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          float* __restrict__ wf, float* __restrict__ bf, int C)
+{
+    __shared__ float red[256];
+    const int k = blockIdx.x;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float wv = w[(long)k * C + c];
+        wf[(long)k * C + c] = wv * scale[c];
+        s += wv * shift[c];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bf[k] = (b ? b[k] : 0.f) + red[0];
+}
+
+// logits [N][HW][K1] (pixel-major) -> pixels_cls_scores [N][K1][HW] (returned to the engine), probabilities
+// [N][K1][HW] (bg = row 0, parts = rows 1..K), pooling masks pm [N][K+3][HW] = {1, fg, bg, part_1..K},
+// arg-max part (1..K) for the fg = max backward, arg-max class (0..K) for binary visibility.
+__global__ __launch_bounds__(256) void bpb_softmax_masks_kernel(const float* __restrict__ logits, float* __restrict__ scores,
+                                                                float* __restrict__ probs, float* __restrict__ pm,
+                                                                unsigned char* __restrict__ argpart,
+                                                                unsigned char* __restrict__ argcls, int N, int HW, int K1)
+{
+    const long total = (long)N * HW;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+        const long n = i / HW, p = i - n * HW;
+        float l[BPB_HEAD_MAXJ], mx = -INFINITY;
+        for (int k = 0; k < K1; ++k) {
+            l[k] = logits[i * K1 + k];
+            mx = fmaxf(mx, l[k]);
+        }
+        float den = 0.f;
+        for (int k = 0; k < K1; ++k) {
+            scores[(n * K1 + k) * HW + p] = l[k];
+            l[k] = expf(l[k] - mx);
+            den += l[k];
+        }
+        float fg = -INFINITY, best = -INFINITY;
+        int ap = 1, ac = 0;
+        for (int k = 0; k < K1; ++k) {
+            const float pr = l[k] / den;
+            probs[(n * K1 + k) * HW + p] = pr;
+            if (pr > best) { best = pr; ac = k; }               // first maximum wins (torch.argmax)
+            if (k >= 1) {
+                if (pr > fg) { fg = pr; ap = k; }                // first maximum wins (torch.max(dim))
+                pm[(n * (K1 + 2) + 2 + k) * HW + p] = pr;
+            } else {
+                pm[(n * (K1 + 2) + 2) * HW + p] = pr;            // background
+            }
+        }
+        pm[(n * (K1 + 2) + 0) * HW + p] = 1.f;
+        pm[(n * (K1 + 2) + 1) * HW + p] = fg;
+        argpart[i] = (unsigned char)ap;
+        argcls[i] = (unsigned char)ac;
+    }
+}
+
+// visibility (bpbreid.py:182-192).  binary: vis[n][k] = any pixel whose arg-max class is k;
+// continuous: vis[n][k] = max_p prob[n][k][p].  Output float [N][K1] (0/1 for binary) + fg = amax over ALL K1.
+__global__ __launch_bounds__(256) void bpb_visibility_kernel(const float* __restrict__ probs,
+                                                             const unsigned char* __restrict__ argcls,
+                                                             float* __restrict__ vis, float* __restrict__ fgvis, int HW,
+                                                             int K1, int binary)
+{
+    __shared__ float red[256];
+    const int n = blockIdx.x;
+    float fgm = -INFINITY;
+    for (int k = 0; k < K1; ++k) {
+        float v = binary ? 0.f : -INFINITY;
+        for (int p = threadIdx.x; p < HW; p += 256) {
+            if (binary) v = fmaxf(v, argcls[(long)n * HW + p] == k ? 1.f : 0.f);
+            else v = fmaxf(v, probs[((long)n * K1 + k) * HW + p]);
+        }
+        red[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 128; o >= 1; o >>= 1) {
+            if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+            __syncthreads();
+        }
+        const float r = red[0];
+        __syncthreads();
+        if (threadIdx.x == 0) vis[(long)n * K1 + k] = r;
+        fgm = fmaxf(fgm, r);
+    }
+    if (threadIdx.x == 0) fgvis[n] = fgm;
+}
+
+// pooled[n][j][c] = (sum over chunks of part) * norm_j ;  j: 0 global (1/HW), 1 fg (1/HW), 2 bg (1/HW),
+// 3.. parts: 1 / clamp(sum_p m_j, 1e-6)  (bpbreid.py:498-501).  Also saves zinv[n][j] = norm_j and the flag
+// `clamped` for the backward.  Deterministic fixed-order sum.
+__global__ __launch_bounds__(256) void bpb_pool_finalize_kernel(const float* __restrict__ part, const float* __restrict__ pm,
+                                                                float* __restrict__ pooled, float* __restrict__ zinv,
+                                                                int nchunks, int J, int HW, int C)
+{
+    __shared__ float red[256];
+    const int n = blockIdx.y, j = blockIdx.x;
+    float norm;
+    if (j < 3) {
+        norm = 1.f / (float)HW;
+    } else {
+        float s = 0.f;
+        for (int p = threadIdx.x; p < HW; p += 256) s += pm[((long)n * J + j) * HW + p];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 128; o >= 1; o >>= 1) {
+            if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        norm = 1.f / fmaxf(red[0], 1e-6f);
+    }
+    if (threadIdx.x == 0) zinv[(long)n * J + j] = (j >= 3 && norm >= 1e6f) ? -norm : norm;   // sign marks an active clamp
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int q = 0; q < nchunks; ++q) s += part[(((long)n * nchunks + q) * J + j) * C + c];
+        pooled[((long)n * J + j) * C + c] = s * norm;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward glue.  Inputs per image n, pixel p:
+//   D[n][p][j]   = sum_c G[n][j][c] x[n][p][c]   for j = 0 fg, 1 bg, 2.. parts   (G = grad of pooled rows 1.., from pixel_dots)
+//   gp[n][j]     = sum_c G_j[c] * pooled_j[c]      (parts only; precomputed by bpb_rowdot)
+// Outputs: dlogit [N][K1][HW]  (softmax backward + external pixel-CE gradient) and nothing else; the
+// pooling coefficients for dx are recomputed from probs/zinv in the dx kernel.
+__global__ __launch_bounds__(256) void bpb_head_bwd_dlogits_kernel(const float* __restrict__ D, const float* __restrict__ probs,
+                                                                   const unsigned char* __restrict__ argpart,
+                                                                   const float* __restrict__ zinv, const float* __restrict__ gp,
+                                                                   const float* __restrict__ dlogit_ext,
+                                                                   float* __restrict__ dlogit, int N, int HW, int K1)
+{
+    const int J = K1 + 2;        // pooled rows: 0 global, 1 fg, 2 bg, 3.. parts
+    const int JD = K1 + 1;       // D rows: fg, bg, parts
+    const long total = (long)N * HW;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+        const long n = i / HW, p = i - n * HW;
+        float pr[BPB_HEAD_MAXJ], dp[BPB_HEAD_MAXJ];
+        const float inv_hw = 1.f / (float)HW;
+        const float dm_fg = D[i * JD + 0] * inv_hw;
+        const float dm_bg = D[i * JD + 1] * inv_hw;
+        const int ap = argpart[i];
+        float dot = 0.f;
+        for (int k = 0; k < K1; ++k) {
+            pr[k] = probs[(n * K1 + k) * HW + p];
+            float d;
+            if (k == 0) {
+                d = dm_bg;
+            } else {
+                const float zi = zinv[n * J + 2 + k];
+                // pooled = S/Z ; dm = (G.x - G.pooled)/Z when the clamp is inactive, (G.x)/Z when active
+                d = zi > 0.f ? (D[i * JD + 1 + k] - gp[n * J + 2 + k]) * zi : D[i * JD + 1 + k] * (-zi);
+                if (k == ap) d += dm_fg;
+            }
+            dp[k] = d;
+            dot += pr[k] * d;
+        }
+        for (int k = 0; k < K1; ++k) {
+            float g = pr[k] * (dp[k] - dot);
+            if (dlogit_ext) g += dlogit_ext[(n * K1 + k) * HW + p];
+            dlogit[(n * K1 + k) * HW + p] = g;
+        }
+    }
+}
+
+// out[r] = sum_c a[r][c]*b[r][c]   (one block per row)
+__global__ __launch_bounds__(256) void bpb_rowdot_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         float* __restrict__ out, int C)
+{
+    __shared__ float red[256];
+    const long r = blockIdx.x;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) s += a[r * C + c] * b[r * C + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[r] = red[0];
+}
+
+// Parameter gradients of the pixel classifier + the per-channel constants of its BatchNorm backward.
+//   Araw[k][c] = sum_{n,p} dlogit_k x[n,p,c]  (= masked_pool partials summed over n, chunks),  L[k] = sum dlogit_k
+//   A = (Araw - mu*L) * invstd ;  S1 = sum_k W[k][c] L[k] ;  S2 = sum_k W[k][c] A[k][c]
+//   dbeta = S1, dgamma = S2, dW[k][c] = gamma*A + beta*L, dbias = L ;  k1 = S1/M, k2 = S2/M
+__global__ __launch_bounds__(256) void bpb_head_bwd_params_kernel(const float* __restrict__ part, int nparts,
+                                                                  const float* __restrict__ dlogit, long npix_total, int HW,
+                                                                  int K1, int C, const float* __restrict__ W,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                  float* __restrict__ dW, float* __restrict__ dbias,
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                  float* __restrict__ k1, float* __restrict__ k2,
+                                                                  int accumulate)
+{
+    __shared__ double L[BPB_HEAD_MAXJ];
+    __shared__ double red[256];
+    // every block recomputes L[k] (K1 * N*HW floats, L2 resident) -- deterministic, no cross-block dependency
+    const long per = npix_total / HW;   // images
+    for (int k = 0; k < K1; ++k) {
+        double s = 0.0;
+        for (long i = threadIdx.x; i < npix_total; i += 256) {
+            const long n = i / HW, p = i - n * HW;
+            s += (double)dlogit[(n * K1 + k) * HW + p];
+        }
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 128; o >= 1; o >>= 1) {
+            if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) L[k] = red[0];
+        __syncthreads();
+    }
+    (void)per;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < C) {
+        const double M = (double)npix_total;
+        double s1 = 0.0, s2 = 0.0;
+        const float g = gamma[c], b = beta[c], mu = mean[c], is = invstd[c];
+        for (int k = 0; k < K1; ++k) {
+            double araw = 0.0;
+            for (int q = 0; q < nparts; ++q) araw += (double)part[((long)q * K1 + k) * C + c];
+            const double a = (araw - (double)mu * L[k]) * (double)is;
+            const double w = (double)W[(long)k * C + c];
+            s1 += w * L[k];
+            s2 += w * a;
+            const float dw = (float)((double)g * a + (double)b * L[k]);
+            dW[(long)k * C + c] = accumulate ? dW[(long)k * C + c] + dw : dw;
+        }
+        dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
+        dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
+        k1[c] = (float)(s1 / M);
+        k2[c] = (float)(s2 / M);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < K1)
+        dbias[threadIdx.x] = accumulate ? dbias[threadIdx.x] + (float)L[threadIdx.x] : (float)L[threadIdx.x];
+}
+
+// dx[n][p][c] (+)= sum_j coef_j[n][p] * G[n][j][c]
+//                 + gamma*invstd * ( sum_k dlogit_k[n][p] W[k][c] - k1[c] - xhat * k2[c] )
+// coef: global 1/HW, fg fgmask/HW, bg bgmask/HW, parts m_j * |zinv_j|.   One block = (image, pixel chunk);
+// threads own channel quads and stream the pixels (same traversal as masked_pool).
+template <int K1>
+__global__ __launch_bounds__(256) void bpb_head_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ G,
+                                                              const float* __restrict__ pm, const float* __restrict__ zinv,
+                                                              const float* __restrict__ dlogit, const float* __restrict__ W,
+                                                              const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, const float* __restrict__ k1,
+                                                              const float* __restrict__ k2, float* __restrict__ dx, int HW,
+                                                              int C, int pix_per_block, int accumulate)
+{
+    constexpr int J = K1 + 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // coef [J][ppb] then dlogit [K1][ppb]
+    const int n = blockIdx.y;
+    const int p_begin = blockIdx.x * pix_per_block, p_end = min(HW, p_begin + pix_per_block);
+    const int np = p_end - p_begin;
+    float* coef = smem;
+    float* dl = smem + J * pix_per_block;
+    const float inv_hw = 1.f / (float)HW;
+    for (int i = threadIdx.x; i < J * pix_per_block; i += 256) {
+        const int j = i / pix_per_block, pp = i - j * pix_per_block;
+        float v = 0.f;
+        if (pp < np) {
+            const float mv = pm[((long)n * J + j) * HW + p_begin + pp];
+            v = j < 3 ? mv * inv_hw : mv * fabsf(zinv[(long)n * J + j]);
+        }
+        coef[i] = v;
+    }
+    for (int i = threadIdx.x; i < K1 * pix_per_block; i += 256) {
+        const int k = i / pix_per_block, pp = i - k * pix_per_block;
+        dl[i] = pp < np ? dlogit[((long)n * K1 + k) * HW + p_begin + pp] : 0.f;
+    }
+    __syncthreads();
+    const int c4 = C >> 2;
+    for (int cq = threadIdx.x; cq < c4; cq += 256) {
+        f32x4 g[J], w[K1];
+#pragma unroll
+        for (int j = 0; j < J; ++j) g[j] = *(const f32x4*)(G + ((long)n * J + j) * C + cq * 4);
+#pragma unroll
+        for (int k = 0; k < K1; ++k) w[k] = *(const f32x4*)(W + (long)k * C + cq * 4);
+        const f32x4 ga = *(const f32x4*)(gamma + cq * 4), mu = *(const f32x4*)(mean + cq * 4);
+        const f32x4 is = *(const f32x4*)(invstd + cq * 4), c1 = *(const f32x4*)(k1 + cq * 4), c2 = *(const f32x4*)(k2 + cq * 4);
+        const long base = ((long)n * HW + p_begin) * C + cq * 4;
+        for (int pp = 0; pp < np; ++pp) {
+            const f32x4 xv = *(const f32x4*)(x + base + (long)pp * C);
+            f32x4 o = {0.f, 0.f, 0.f, 0.f}, dz = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const float cf = coef[j * pix_per_block + pp];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += cf * g[j][e];
+            }
+#pragma unroll
+            for (int k = 0; k < K1; ++k) {
+                const float d = dl[k * pix_per_block + pp];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dz[e] += d * w[k][e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += ga[e] * is[e] * (dz[e] - c1[e] - (xv[e] - mu[e]) * is[e] * c2[e]);
+            float* dst = dx + base + (long)pp * C;
+            if (accumulate) {
+                const f32x4 old = *(const f32x4*)dst;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += old[e];
+            }
+            *(f32x4*)dst = o;
+        }
+    }
+}
+
+// ------------------------------------ C ABI ------------------------------------------
+#define BPB_DISPATCH_J(J_, MACRO)          \
+    switch (J_) {                          \
+        case 1: MACRO(1); break;           \
+        case 2: MACRO(2); break;           \
+        case 3: MACRO(3); break;           \
+        case 4: MACRO(4); break;           \
+        case 5: MACRO(5); break;           \
+        case 6: MACRO(6); break;           \
+        case 7: MACRO(7); break;           \
+        case 8: MACRO(8); break;           \
+        case 9: MACRO(9); break;           \
+        case 10: MACRO(10); break;         \
+        case 11: MACRO(11); break;         \
+        case 12: MACRO(12); break;         \
+        default: return bpb_set_error(-1, "%s: J=%d out of range [1,12]", __func__, J_); \
+    }
+
+static int head_grid(long total)
+{
+    long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    return g < 1 ? 1 : (int)g;
+}
+
+extern "C" {
+
+int bpb_head_init(void)
+{
+#define BPB_ATTR(JJ)                                                                                                  \
+    {                                                                                                                 \
+        hipError_t e = hipFuncSetAttribute((const void*)bpb_pixel_dots_kernel<JJ>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                           160 * 1024);                                                               \
+        if (e != hipSuccess) return bpb_set_error((int)e, "bpb_head_init: %s", hipGetErrorString(e));                 \
+    }
+    BPB_ATTR(1) BPB_ATTR(2) BPB_ATTR(3) BPB_ATTR(4) BPB_ATTR(5) BPB_ATTR(6)
+    BPB_ATTR(7) BPB_ATTR(8) BPB_ATTR(9) BPB_ATTR(10) BPB_ATTR(11) BPB_ATTR(12)
+#undef BPB_ATTR
+    return 0;
+}
+
+// out[n][p][j] = sum_c w[n*w_image_stride + j*C + c] x[n][p][c] + bias[j]
+int bpb_pixel_dots(const float* x, const float* w, long w_image_stride, const float* bias, float* out, int N, int HW, int C,
+                   int J, hipStream_t stream)
+{
+    BPB_REQUIRE(C % 4 == 0 && N >= 1 && HW >= 1, "bpb_pixel_dots: bad sizes");
+    BPB_REQUIRE((long)J * C * 4 <= 150 * 1024, "bpb_pixel_dots: weight rows do not fit in LDS");
+    int ppb = 64;
+    while (ppb > 16 && (long)N * bpb_cdiv(HW, ppb) < 1024) ppb >>= 1;
+    const dim3 grid(bpb_cdiv(HW, ppb), N);
+    const int lds = J * C * 4;
+#define BPB_PD(JJ) \
+    hipLaunchKernelGGL(bpb_pixel_dots_kernel<JJ>, grid, dim3(256), lds, stream, x, w, w_image_stride, bias, out, HW, C, ppb)
+    BPB_DISPATCH_J(J, BPB_PD)
+#undef BPB_PD
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+// part must hold N * nchunks * J * C floats; returns nchunks through *nchunks_out (call with part == nullptr to query).
+int bpb_masked_pool(const float* x, const float* m, float* part, int N, int HW, int C, int J, int* nchunks_out,
+                    hipStream_t stream)
+{
+    BPB_REQUIRE(C % 4 == 0 && N >= 1 && HW >= 1, "bpb_masked_pool: bad sizes");
+    int ppb = 128;
+    while (ppb > 16 && (long)N * bpb_cdiv(HW, ppb) < 512) ppb >>= 1;
+    const int nchunks = bpb_cdiv(HW, ppb);
+    if (nchunks_out) *nchunks_out = nchunks;
+    if (!part) return 0;
+    const dim3 grid(nchunks, N);
+    const int lds = J * ppb * 4;
+#define BPB_MP(JJ) hipLaunchKernelGGL(bpb_masked_pool_kernel<JJ>, grid, dim3(256), lds, stream, x, m, part, HW, C, ppb)
+    BPB_DISPATCH_J(J, BPB_MP)
+#undef BPB_MP
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_fold_bn(const float* w, const float* b, const float* scale, const float* shift, float* wf, float* bf, int K1, int C,
+                hipStream_t stream)
+{
+    hipLaunchKernelGGL(bpb_fold_bn_kernel, dim3(K1), dim3(256), 0, stream, w, b, scale, shift, wf, bf, C);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_softmax_masks(const float* logits, float* scores, float* probs, float* pm, unsigned char* argpart,
+                      unsigned char* argcls, int N, int HW, int K1, hipStream_t stream)
+{
+    BPB_REQUIRE(K1 >= 2 && K1 <= BPB_HEAD_MAXJ - 2, "bpb_softmax_masks: K+1=%d out of range", K1);
+    hipLaunchKernelGGL(bpb_softmax_masks_kernel, dim3(head_grid((long)N * HW)), dim3(256), 0, stream, logits, scores, probs,
+                       pm, argpart, argcls, N, HW, K1);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_visibility(const float* probs, const unsigned char* argcls, float* vis, float* fgvis, int N, int HW, int K1,
+                   int binary, hipStream_t stream)
+{
+    hipLaunchKernelGGL(bpb_visibility_kernel, dim3(N), dim3(256), 0, stream, probs, argcls, vis, fgvis, HW, K1, binary);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_pool_finalize(const float* part, const float* pm, float* pooled, float* zinv, int N, int nchunks, int J, int HW,
+                      int C, hipStream_t stream)
+{
+    hipLaunchKernelGGL(bpb_pool_finalize_kernel, dim3(J, N), dim3(256), 0, stream, part, pm, pooled, zinv, nchunks, J, HW, C);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_rowdot(const float* a, const float* b, float* out, int rows, int C, hipStream_t stream)
+{
+    hipLaunchKernelGGL(bpb_rowdot_kernel, dim3(rows), dim3(256), 0, stream, a, b, out, C);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_head_bwd_dlogits(const float* D, const float* probs, const unsigned char* argpart, const float* zinv,
+                         const float* gp, const float* dlogit_ext, float* dlogit, int N, int HW, int K1, hipStream_t stream)
+{
+    BPB_REQUIRE(K1 >= 2 && K1 <= BPB_HEAD_MAXJ - 2, "bpb_head_bwd_dlogits: K+1=%d out of range", K1);
+    hipLaunchKernelGGL(bpb_head_bwd_dlogits_kernel, dim3(head_grid((long)N * HW)), dim3(256), 0, stream, D, probs, argpart,
+                       zinv, gp, dlogit_ext, dlogit, N, HW, K1);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_head_bwd_params(const float* part, int nparts, const float* dlogit, int N, int HW, int K1, int C, const float* W,
+                        const float* gamma, const float* beta, const float* mean, const float* invstd, float* dW,
+                        float* dbias, float* dgamma, float* dbeta, float* k1, float* k2, int accumulate, hipStream_t stream)
+{
+    hipLaunchKernelGGL(bpb_head_bwd_params_kernel, dim3(bpb_cdiv(C, 256)), dim3(256), 0, stream, part, nparts, dlogit,
+                       (long)N * HW, HW, K1, C, W, gamma, beta, mean, invstd, dW, dbias, dgamma, dbeta, k1, k2, accumulate);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_head_bwd_dx(const float* x, const float* G, const float* pm, const float* zinv, const float* dlogit, const float* W,
+                    const float* gamma, const float* mean, const float* invstd, const float* k1, const float* k2, float* dx,
+                    int N, int HW, int C, int K1, int accumulate, hipStream_t stream)
+{
+    BPB_REQUIRE(C % 4 == 0, "bpb_head_bwd_dx: C must be a multiple of 4");
+    int ppb = 128;
+    while (ppb > 16 && (long)N * bpb_cdiv(HW, ppb) < 512) ppb >>= 1;
+    const dim3 grid(bpb_cdiv(HW, ppb), N);
+    const int lds = (2 * K1 + 2) * ppb * 4;
+#define BPB_DX(KK) \
+    hipLaunchKernelGGL(bpb_head_bwd_dx_kernel<KK>, grid, dim3(256), lds, stream, x, G, pm, zinv, dlogit, W, gamma, mean, \
+                       invstd, k1, k2, dx, HW, C, ppb, accumulate)
+    switch (K1) {
+        case 2: BPB_DX(2); break;
+        case 3: BPB_DX(3); break;
+        case 4: BPB_DX(4); break;
+        case 5: BPB_DX(5); break;
+        case 6: BPB_DX(6); break;
+        case 7: BPB_DX(7); break;
+        case 8: BPB_DX(8); break;
+        case 9: BPB_DX(9); break;
+        default: return bpb_set_error(-1, "bpb_head_bwd_dx: K+1=%d out of range [2,9]", K1);
+    }
+#undef BPB_DX
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+}   // extern "C"

@@ -1,0 +1,472 @@
+// BatchNorm2d (training + eval) fused with residual/fuse sums, nearest upsampling and ReLU.
+//
+// Every post-convolution elementwise stage of HRNet / ResNet on the path has the form
+//     out = act( sum_t  affine_t( nearest_up_t( src_t ) ) ),   t < 4
+// with affine_t = BatchNorm (batch or running statistics) or identity, act = ReLU or identity:
+//   BasicBlock / Bottleneck tails      torchreid/models/hrnet.py:80-96, 117-137; resnet.py:133-154
+//   transition / stem conv-BN-ReLU     hrnet.py:533-538, 458-481
+//   HighResolutionModule fuse sums     hrnet.py:269-277 (+ nn.Upsample nearest, :231)
+// One HBM-bound pass reads each operand once and writes `out` once (the reference does one pass
+// per BN, per add, per upsample and per ReLU).  BatchNorm batch statistics come from per-tile fp64
+// partials emitted by the conv epilogue (conv_igemm.hip) -> bpb_bn_finalize -> (scale, shift).
+#include "bpb_common.h"
+
+#define BPB_MAX_TERMS 4
+
+// ---- (1) batch statistics -> affine, running stats (nn.BatchNorm2d training semantics) ----------
+// partials: [nparts][2][C] doubles (sum, sumsq).  count = elements per channel.
+// Outputs: scale = gamma*invstd, shift = beta - mean*scale, mean, invstd (saved for backward);
+// running_mean = (1-m)*running_mean + m*mean; running_var uses the unbiased variance (torch semantics).
+__global__ __launch_bounds__(256) void bpb_bn_finalize_kernel(const double* __restrict__ partials, int nparts, int C,
+                                                              double count, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps, float momentum,
+                                                              float* __restrict__ scale, float* __restrict__ shift,
+                                                              float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                              float* __restrict__ running_mean,
+                                                              float* __restrict__ running_var)
+{
+    __shared__ double red[2][8][32];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int rg = threadIdx.x >> 5;
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+        for (int p = rg; p < nparts; p += 8) {
+            s += partials[((size_t)p * 2 + 0) * C + c];
+            q += partials[((size_t)p * 2 + 1) * C + c];
+        }
+    }
+    red[0][rg][threadIdx.x & 31] = s;
+    red[1][rg][threadIdx.x & 31] = q;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        s = 0.0;
+        q = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            s += red[0][i][threadIdx.x];
+            q += red[1][i][threadIdx.x];
+        }
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        const float sc = g * invstd;
+        scale[c] = sc;
+        shift[c] = b - (float)mean * sc;
+        mean_out[c] = (float)mean;
+        invstd_out[c] = invstd;
+        if (running_mean) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
+// eval mode: affine from running statistics
+__global__ void bpb_bn_eval_affine_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                          const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                          float eps, float* __restrict__ scale, float* __restrict__ shift)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const float invstd = 1.f / sqrtf(running_var[c] + eps);
+        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        scale[c] = g * invstd;
+        shift[c] = b - running_mean[c] * scale[c];
+    }
+}
+
+// per-channel (sum, sumsq) partials of an NHWC tensor: used where no conv epilogue produced them
+// (pixel-classifier BN over the concatenated feature map, bpbreid.py:379,384).
+__global__ __launch_bounds__(256) void bpb_channel_stats_kernel(const float* __restrict__ x, long P, int C,
+                                                                double* __restrict__ partials)
+{
+    // block b handles pixels [b*ppb, (b+1)*ppb); thread t owns channel quads cq = t, t+256, ... and all pixels of the block
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const int c4 = C >> 2;
+    const long ppb = (P + gridDim.x - 1) / gridDim.x;
+    const long p0 = blockIdx.x * ppb, p1 = min(P, p0 + ppb);
+    // rows-of-pixels x channel-quads thread layout
+    const int tx = c4 >= 256 ? 256 : c4;         // threads along channels
+    const int rows = 256 / tx;                   // pixel rows per sweep; threads with trow >= rows idle
+    const int tcq = threadIdx.x % tx, trow = threadIdx.x / tx;
+    double* red = (double*)smem_f;               // [thread][8]
+    for (int cq = tcq; cq < c4; cq += tx) {
+        double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+        for (long p = p0 + trow; trow < rows && p < p1; p += rows) {
+            const f32x4 v = *(const f32x4*)(x + p * C + cq * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s[e] += (double)v[e];
+                q[e] += (double)v[e] * (double)v[e];
+            }
+        }
+        if (rows > 1) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                red[(threadIdx.x) * 8 + e] = s[e];
+                red[(threadIdx.x) * 8 + 4 + e] = q[e];
+            }
+            __syncthreads();
+            if (trow == 0) {
+                for (int r = 1; r < rows; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s[e] += red[(r * tx + tcq) * 8 + e];
+                        q[e] += red[(r * tx + tcq) * 8 + 4 + e];
+                    }
+            }
+        }
+        if (trow == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                partials[((size_t)blockIdx.x * 2 + 0) * C + cq * 4 + e] = s[e];
+                partials[((size_t)blockIdx.x * 2 + 1) * C + cq * 4 + e] = q[e];
+            }
+        }
+    }
+}
+
+// ---- (2) fused forward: out = act(sum_t affine_t(up_t(src_t))) -----------------------------------
+struct BpbFuseArgs {
+    float* out;                         // [N][H][W][C]
+    const float* src[BPB_MAX_TERMS];    // term t: [N][H>>up][W>>up][C]
+    const float* scale[BPB_MAX_TERMS];  // nullptr -> identity term
+    const float* shift[BPB_MAX_TERMS];
+    int up[BPB_MAX_TERMS];              // log2 nearest-upsample factor
+    int nterms;
+    int N, H, W, C;
+    int relu;
+    unsigned magic_w, magic_h;          // ceil(2^32 / W), ceil(2^32 / H)
+};
+
+__device__ __forceinline__ unsigned bpb_fdiv2(unsigned x, unsigned d, unsigned magic)
+{
+    return d == 1 ? x : __umulhi(x, magic);
+}
+
+__global__ __launch_bounds__(256) void bpb_fuse_fwd_kernel(BpbFuseArgs A)
+{
+    const int c4 = A.C >> 2;
+    const long total = (long)A.N * A.H * A.W * c4;
+    bool any_up = false;
+#pragma unroll
+    for (int t = 0; t < BPB_MAX_TERMS; ++t)
+        if (t < A.nterms && A.up[t] > 0) any_up = true;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+        const int cq = (int)(i % c4);
+        const long p = i / c4;
+        int n = 0, h = 0, w = 0;
+        if (any_up) {
+            const unsigned pw = bpb_fdiv2((unsigned)p, A.W, A.magic_w);
+            w = (int)((unsigned)p - pw * A.W);
+            const unsigned ph = bpb_fdiv2(pw, A.H, A.magic_h);
+            h = (int)(pw - ph * A.H);
+            n = (int)ph;
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < BPB_MAX_TERMS; ++t) {
+            if (t < A.nterms) {
+                long sp = p;
+                if (A.up[t] > 0) sp = ((long)n * (A.H >> A.up[t]) + (h >> A.up[t])) * (A.W >> A.up[t]) + (w >> A.up[t]);
+                f32x4 v = *(const f32x4*)(A.src[t] + sp * A.C + cq * 4);
+                if (A.scale[t]) {
+                    const f32x4 sc = *(const f32x4*)(A.scale[t] + cq * 4);
+                    const f32x4 sh = *(const f32x4*)(A.shift[t] + cq * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[e] + sh[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += v[e];
+            }
+        }
+        if (A.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = acc[e] > 0.f ? acc[e] : 0.f;
+        }
+        *(f32x4*)(A.out + p * A.C + cq * 4) = acc;
+    }
+}
+
+// ---- (3) backward of one term ------------------------------------------------------------------
+// G[q][c] = sum over the 2^up x 2^up window of dout * (out > 0 if relu).
+struct BpbTermBwdArgs {
+    const float* dout;      // [N][H][W][C] gradient wrt `out`
+    const float* out;       // forward output (ReLU mask), may be nullptr when relu == 0
+    const float* src;       // forward input of the term (conv raw output) [N][Hs][Ws][C]; BN terms only
+    const float* mean;      // BN terms: saved batch mean / invstd / scale(gamma*invstd)
+    const float* invstd;
+    const float* scale;
+    const float* c1;        // BN apply: per-channel sum(G)/M and sum(G*xhat)/M
+    const float* c2;
+    float* dsrc;            // gradient wrt src
+    double* partials;       // BN reduce: [nblocks][2][C]
+    int N, Hs, Ws, C, up;   // src spatial dims; out dims are Hs<<up, Ws<<up
+    int relu, accumulate;
+    unsigned magic_w, magic_h;   // for Ws, Hs
+};
+
+__device__ __forceinline__ f32x4 bpb_window_grad(const BpbTermBwdArgs& A, long q, int cq)
+{
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    if (A.up == 0) {
+        g = *(const f32x4*)(A.dout + q * A.C + cq * 4);
+        if (A.relu) {
+            const f32x4 o = *(const f32x4*)(A.out + q * A.C + cq * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+        }
+        return g;
+    }
+    const unsigned pw = bpb_fdiv2((unsigned)q, A.Ws, A.magic_w);
+    const int w = (int)((unsigned)q - pw * A.Ws);
+    const unsigned ph = bpb_fdiv2(pw, A.Hs, A.magic_h);
+    const int h = (int)(pw - ph * A.Hs), n = (int)ph;
+    const int f = 1 << A.up, H = A.Hs << A.up, W = A.Ws << A.up;
+    for (int dh = 0; dh < f; ++dh)
+        for (int dw = 0; dw < f; ++dw) {
+            const long p = ((long)n * H + (h * f + dh)) * W + (w * f + dw);
+            f32x4 v = *(const f32x4*)(A.dout + p * A.C + cq * 4);
+            if (A.relu) {
+                const f32x4 o = *(const f32x4*)(A.out + p * A.C + cq * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = o[e] > 0.f ? v[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] += v[e];
+        }
+    return g;
+}
+
+// identity term: dsrc (+)= G
+__global__ __launch_bounds__(256) void bpb_term_bwd_identity_kernel(BpbTermBwdArgs A)
+{
+    const int c4 = A.C >> 2;
+    const long total = (long)A.N * A.Hs * A.Ws * c4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+        const int cq = (int)(i % c4);
+        const long q = i / c4;
+        f32x4 g = bpb_window_grad(A, q, cq);
+        float* d = A.dsrc + q * A.C + cq * 4;
+        if (A.accumulate) {
+            const f32x4 old = *(const f32x4*)d;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] += old[e];
+        }
+        *(f32x4*)d = g;
+    }
+}
+
+// BN term, pass 1: per-block partials of (sum G, sum G*xhat) per channel
+__global__ __launch_bounds__(256) void bpb_term_bwd_bn_reduce_kernel(BpbTermBwdArgs A)
+{
+    __shared__ double red[256 * 8];
+    const int c4 = A.C >> 2;
+    const long P = (long)A.N * A.Hs * A.Ws;
+    const long ppb = (P + gridDim.x - 1) / gridDim.x;
+    const long p0 = blockIdx.x * ppb, p1 = min(P, p0 + ppb);
+    const int tx = c4 >= 256 ? 256 : c4;
+    const int rows = 256 / tx;             // threads with trow >= rows idle (c4 need not be a power of two)
+    const int tcq = threadIdx.x % tx, trow = threadIdx.x / tx;
+    for (int cq = tcq; cq < c4; cq += tx) {
+        const f32x4 mu = *(const f32x4*)(A.mean + cq * 4);
+        const f32x4 is = *(const f32x4*)(A.invstd + cq * 4);
+        float s[4] = {0, 0, 0, 0}, sx[4] = {0, 0, 0, 0};
+        double ds[4] = {0, 0, 0, 0}, dsx[4] = {0, 0, 0, 0};
+        int cnt = 0;
+        for (long q = p0 + trow; trow < rows && q < p1; q += rows) {
+            const f32x4 g = bpb_window_grad(A, q, cq);
+            const f32x4 x = *(const f32x4*)(A.src + q * A.C + cq * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s[e] += g[e];
+                sx[e] += g[e] * ((x[e] - mu[e]) * is[e]);
+            }
+            if (++cnt == 64) {   // flush fp32 running sums into fp64 every 64 pixels
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ds[e] += s[e]; dsx[e] += sx[e]; s[e] = 0.f; sx[e] = 0.f; }
+                cnt = 0;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ds[e] += s[e]; dsx[e] += sx[e]; }
+        if (rows > 1) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                red[threadIdx.x * 8 + e] = ds[e];
+                red[threadIdx.x * 8 + 4 + e] = dsx[e];
+            }
+            __syncthreads();
+            if (trow == 0)
+                for (int r = 1; r < rows; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ds[e] += red[(r * tx + tcq) * 8 + e];
+                        dsx[e] += red[(r * tx + tcq) * 8 + 4 + e];
+                    }
+        }
+        if (trow == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                A.partials[((size_t)blockIdx.x * 2 + 0) * A.C + cq * 4 + e] = ds[e];
+                A.partials[((size_t)blockIdx.x * 2 + 1) * A.C + cq * 4 + e] = dsx[e];
+            }
+        }
+    }
+}
+
+// BN term, between passes: dbeta = sum G, dgamma = sum G*xhat -> parameter grads (+ optional accumulate)
+// and the per-channel constants c1 = dbeta / M, c2 = dgamma / M for the apply pass.
+__global__ __launch_bounds__(256) void bpb_bn_bwd_finalize_kernel(const double* __restrict__ partials, int nparts, int C,
+                                                                  double count, float* __restrict__ dgamma,
+                                                                  float* __restrict__ dbeta, int accumulate,
+                                                                  float* __restrict__ c1, float* __restrict__ c2)
+{
+    __shared__ double red[2][8][32];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int rg = threadIdx.x >> 5;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int p = rg; p < nparts; p += 8) {
+            s += partials[((size_t)p * 2 + 0) * C + c];
+            q += partials[((size_t)p * 2 + 1) * C + c];
+        }
+    red[0][rg][threadIdx.x & 31] = s;
+    red[1][rg][threadIdx.x & 31] = q;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        s = 0.0;
+        q = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            s += red[0][i][threadIdx.x];
+            q += red[1][i][threadIdx.x];
+        }
+        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s : (float)s;
+        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)q : (float)q;
+        c1[c] = (float)(s / count);
+        c2[c] = (float)(q / count);
+    }
+}
+
+// BN term, pass 2: dsrc = scale * (G - c1 - xhat * c2)
+__global__ __launch_bounds__(256) void bpb_term_bwd_bn_apply_kernel(BpbTermBwdArgs A)
+{
+    const int c4 = A.C >> 2;
+    const long total = (long)A.N * A.Hs * A.Ws * c4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+        const int cq = (int)(i % c4);
+        const long q = i / c4;
+        const f32x4 g = bpb_window_grad(A, q, cq);
+        const f32x4 x = *(const f32x4*)(A.src + q * A.C + cq * 4);
+        const f32x4 mu = *(const f32x4*)(A.mean + cq * 4);
+        const f32x4 is = *(const f32x4*)(A.invstd + cq * 4);
+        const f32x4 sc = *(const f32x4*)(A.scale + cq * 4);
+        const f32x4 k1 = *(const f32x4*)(A.c1 + cq * 4);
+        const f32x4 k2 = *(const f32x4*)(A.c2 + cq * 4);
+        f32x4 d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = sc[e] * (g[e] - k1[e] - (x[e] - mu[e]) * is[e] * k2[e]);
+        float* o = A.dsrc + q * A.C + cq * 4;
+        if (A.accumulate) {
+            const f32x4 old = *(const f32x4*)o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] += old[e];
+        }
+        *(f32x4*)o = d;
+    }
+}
+
+// eval-mode / frozen-stat BN term backward is not on the training path and is not provided.
+
+// ------------------------------------ C ABI ------------------------------------------
+static int ew_grid(long total_vec)
+{
+    long g = (total_vec + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" {
+
+int bpb_bn_finalize(const double* partials, int nparts, int C, double count, const float* gamma, const float* beta,
+                    float eps, float momentum, float* scale, float* shift, float* mean, float* invstd,
+                    float* running_mean, float* running_var, hipStream_t stream)
+{
+    BPB_REQUIRE(nparts >= 1 && C >= 1 && count >= 1.0, "bpb_bn_finalize: bad sizes");
+    hipLaunchKernelGGL(bpb_bn_finalize_kernel, dim3(bpb_cdiv(C, 32)), dim3(256), 0, stream, partials, nparts, C, count,
+                       gamma, beta, eps, momentum, scale, shift, mean, invstd, running_mean, running_var);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* scale, float* shift, hipStream_t stream)
+{
+    BPB_REQUIRE(C >= 1, "bpb_bn_eval_affine: C");
+    hipLaunchKernelGGL(bpb_bn_eval_affine_kernel, dim3(bpb_cdiv(C, 256)), dim3(256), 0, stream, C, gamma, beta,
+                       running_mean, running_var, eps, scale, shift);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+// partials must hold nblocks*2*C doubles.  C % 4 == 0.
+int bpb_channel_stats(const float* x, long P, int C, double* partials, int nblocks, hipStream_t stream)
+{
+    BPB_REQUIRE(C % 4 == 0 && P >= 1 && nblocks >= 1, "bpb_channel_stats: bad sizes");
+    hipLaunchKernelGGL(bpb_channel_stats_kernel, dim3(nblocks), dim3(256), 256 * 8 * sizeof(double), stream, x, P, C,
+                       partials);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_fuse_fwd(const BpbFuseArgs* a, hipStream_t stream)
+{
+    BPB_REQUIRE(a->nterms >= 1 && a->nterms <= BPB_MAX_TERMS, "bpb_fuse_fwd: nterms=%d", a->nterms);
+    BPB_REQUIRE(a->C % 4 == 0, "bpb_fuse_fwd: C must be a multiple of 4");
+    for (int t = 0; t < a->nterms; ++t)
+        BPB_REQUIRE(a->up[t] >= 0 && (a->H % (1 << a->up[t])) == 0 && (a->W % (1 << a->up[t])) == 0,
+                    "bpb_fuse_fwd: output dims must be multiples of the upsample factor");
+    const long total = (long)a->N * a->H * a->W * (a->C / 4);
+    BPB_REQUIRE(total < (1L << 32), "bpb_fuse_fwd: tensor too large for 32-bit pixel index");
+    hipLaunchKernelGGL(bpb_fuse_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, *a);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+// mode 0: identity term, 1: BN reduce (nblocks partial rows), 2: BN apply
+int bpb_term_bwd(const BpbTermBwdArgs* a, int mode, int nblocks, hipStream_t stream)
+{
+    BPB_REQUIRE(a->C % 4 == 0, "bpb_term_bwd: C must be a multiple of 4");
+    const long total = (long)a->N * a->Hs * a->Ws * (a->C / 4);
+    if (mode == 0) {
+        hipLaunchKernelGGL(bpb_term_bwd_identity_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, *a);
+    } else if (mode == 1) {
+        BPB_REQUIRE(nblocks >= 1, "bpb_term_bwd: nblocks");
+        hipLaunchKernelGGL(bpb_term_bwd_bn_reduce_kernel, dim3(nblocks), dim3(256), 0, stream, *a);
+    } else if (mode == 2) {
+        hipLaunchKernelGGL(bpb_term_bwd_bn_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, *a);
+    } else {
+        return bpb_set_error(-1, "bpb_term_bwd: mode %d", mode);
+    }
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_bn_bwd_finalize(const double* partials, int nparts, int C, double count, float* dgamma, float* dbeta,
+                        int accumulate, float* c1, float* c2, hipStream_t stream)
+{
+    BPB_REQUIRE(nparts >= 1 && C >= 1, "bpb_bn_bwd_finalize: bad sizes");
+    hipLaunchKernelGGL(bpb_bn_bwd_finalize_kernel, dim3(bpb_cdiv(C, 32)), dim3(256), 0, stream, partials, nparts, C,
+                       count, dgamma, dbeta, accumulate, c1, c2);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+}   // extern "C"

@@ -1,0 +1,78 @@
+// Shared definitions for the bpbreid_amd HIP library (gfx950 / MI355X only).
+//
+// Conventions (SURVEY.md section 8b "C-ABI"):
+//  * every entry point is extern "C", takes plain pointers / sizes / a hipStream_t, allocates
+//    nothing persistent, keeps no global state, enqueues on the passed stream only;
+//  * return 0 on success, negative = argument error (checked before launch), positive =
+//    hipError_t from the launch; bpb_last_error() gives a thread-local message.
+//  * activations are fp32 NHWC ("channels-last") in HBM: channel is the unit-stride dim so a
+//    wave's 64 lanes read/write contiguous channel runs (coalesced 128-B+ segments) and the
+//    MFMA A/B fragments are 16-byte vector loads.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+
+extern "C" const char* bpb_last_error(void);
+int bpb_set_error(int code, const char* fmt, ...);
+
+#define BPB_REQUIRE(cond, ...)                         \
+    do {                                               \
+        if (!(cond)) return bpb_set_error(-1, __VA_ARGS__); \
+    } while (0)
+
+#define BPB_LAUNCH_OK()                                                          \
+    do {                                                                         \
+        hipError_t e__ = hipGetLastError();                                      \
+        if (e__ != hipSuccess) return bpb_set_error((int)e__, "%s: %s", __func__, hipGetErrorString(e__)); \
+    } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// pointers that come out of descriptor structs are generic ("flat") to the compiler; these casts make the
+// accesses global_load/global_store (vmcnt only) instead of flat_* (vmcnt + lgkmcnt)
+#define BPB_GLOBAL __attribute__((address_space(1)))
+typedef const float BPB_GLOBAL* bpb_gcf;
+typedef float BPB_GLOBAL* bpb_gf;
+#define BPB_GLD4(p) (*(const f32x4 BPB_GLOBAL*)(p))
+#define BPB_GST4(p) (*(f32x4 BPB_GLOBAL*)(p))
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int bpb_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------
+// Descriptor of one implicit-GEMM convolution problem.  Lives in DEVICE memory; a launch takes an
+// array of them ("grouped launch": independent branches of an HRNet module share one launch so
+// that 256 CUs stay filled).
+//
+//   y[n, a*osh+ooh, b*osw+oow, :] (+)= sum_t  x[n, a*sa + dh_t + ih0, b*sa + dw_t + iw0, :] . W_t
+//
+// covers forward convs (any R,S,stride,pad), stride-1 dgrad and the parity classes of strided
+// dgrad with one kernel.  W is pre-packed as [tap][Cin/4][Cout][4] (k-quad innermost) so the
+// MFMA B fragment of four consecutive k-steps is one 16-byte load.
+// ---------------------------------------------------------------------------------------
+struct BpbConvProb {
+    const float* x;
+    const float* w;
+    float* y;
+    const float* bias;      // optional [Cout]
+    double* stats;          // optional [n_mtiles][2][Cout] per-tile (sum, sumsq) partials for BatchNorm
+    int N, Hi, Wi, Cin;     // input tensor dims (Cin multiple of 8, or == 4)
+    int Ho, Wo, Cout;       // output tensor dims
+    int A, B;               // logical output grid handled by this problem
+    int osh, osw, ooh, oow; // logical -> output coordinate map
+    int sa;                 // input step per logical step
+    int ih0, iw0;           // input origin
+    // regular tap grid: tap (i, j), i < Rt, j < St reads input offset (dh0 + dhs*i, dw0 + dws*j) >= 0 relative to
+    // (ih0, iw0) and uses packed-weight slice w0 + wrs*i + wss*j.  Covers full filters (forward, stride-1 dgrad)
+    // and the per-parity tap subsets of strided dgrad without any table lookup in the inner loop.
+    int Rt, St, dh0, dhs, dw0, dws, w0, wrs, wss;
+    int lTI, lTH, lTW;      // log2 of the M-tile factorisation TI x TH x TW (= 256 pixels)
+    int HH, HW;             // halo tile dims
+    int CK, LD;             // channel chunk staged per pass and LDS row pitch (floats)
+    int tiles_a, tiles_b, n_mtiles, n_ntiles;
+    int blk_begin;          // first blockIdx of this problem inside a grouped launch
+    int accumulate;         // y += result
+    unsigned magic_hw, magic_hh;   // ceil(2^32/d) for d = HW, HH (staging index split without idiv)
+};

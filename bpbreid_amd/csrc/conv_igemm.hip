@@ -1,0 +1,563 @@
+// Implicit-GEMM convolution on the fp32 MFMA pipe of gfx950 (v_mfma_f32_32x32x2_f32).
+//
+// Replaces, on the BPBReID hot path, every nn.Conv2d the reference dispatches to cuDNN/MIOpen
+// (torchreid/models/hrnet.py:61-64,104-110,184,223,240-250,319-323,459-481 and
+//  torchreid/models/resnet.py:31-49,211-216): forward, data-gradient and weight-gradient.
+//
+// Why fp32 MFMA: the contract is 1e-4 parity with an fp32 CPU oracle through ~320 conv+BN
+// layers.  v_mfma_f32_32x32x2_f32 is bit-exactly an fp32 fma chain (157 TF peak); bf16 inputs
+// cannot hold the tolerance.  The roofline for these kernels is therefore
+// the fp32-matrix peak, 157.3 TFLOP/s.
+//
+// Data layout: activations NHWC fp32.  One workgroup = 4 waves = a 256-pixel x (32*NT)-channel
+// output tile.  The (TI x TH x TW) pixel tile's input halo for a chunk of CK input channels is
+// staged once in LDS ([halo pixel][CK + 4 pad] -> conflict-free 16-byte fragment reads) and
+// reused by every filter tap (9x reuse for 3x3).  MFMA operand packing: for one 16-byte LDS read
+// lanes 0-31 hold channels c..c+3 of pixel (lane&31) and lanes 32-63 channels c+4..c+7, which is
+// exactly the A fragment of four consecutive 32x32x2 MFMAs; the weights are pre-packed
+// [tap][Cin/4][Cout][4] so that the matching B fragments are one coalesced 16-byte global load
+// (weights are L2/L1 resident; they never touch LDS).  Operands for k-group j+1 are fetched
+// into registers before the MFMAs of k-group j issue.
+#include "bpb_common.h"
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ unsigned bpb_fdiv(unsigned x, unsigned d, unsigned magic)
+{
+    return d == 1 ? x : __umulhi(x, magic);
+}
+
+template <int NT, bool C4>
+__global__ __launch_bounds__(256) void bpb_conv_igemm_kernel(const BpbConvProb* __restrict__ probs, int nprobs)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int bid = blockIdx.x;
+    int pi = 0;
+    for (int i = 1; i < nprobs; ++i)
+        if (bid >= probs[i].blk_begin) pi = i;
+    const BpbConvProb P = probs[pi];   // by value: the whole descriptor sits in SGPRs, no reloads in the loops
+    bid -= P.blk_begin;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int lTW = P.lTW, lTH = P.lTH, lTI = P.lTI;
+    const int TWm = (1 << lTW) - 1, THm = (1 << lTH) - 1;
+    const int ntile = bid % P.n_ntiles, mtile = bid / P.n_ntiles;
+    const int tb = mtile % P.tiles_b, t2 = mtile / P.tiles_b;
+    const int ta = t2 % P.tiles_a, tn = t2 / P.tiles_a;
+    const int n0 = tn << lTI, a0 = ta << lTH, b0 = tb << lTW;
+    const int LD = P.LD, HWd = P.HW, HH = P.HH, sa = P.sa;
+    const int Cin = P.Cin, Cout = P.Cout, cin4 = Cin >> 2;
+    const int Rt = P.Rt, St = P.St, ntaps = Rt * St;
+    const bpb_gcf gx = (bpb_gcf)P.x;
+    const bpb_gcf gw = (bpb_gcf)P.w;
+
+    int pixoff[2];   // byte offset of this lane's pixel (per 32-pixel sub-tile) inside the halo tile
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = wave * 64 + mt * 32 + l31;
+        const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
+        pixoff[mt] = (((ti * HH + th * sa) * HWd + tw * sa) * LD) * 4 + (C4 ? 0 : half * 16);
+    }
+    const int cout_l = ntile * NT * 32 + l31;
+    int wcol[NT];    // clamped output-channel index for the weight loads (columns >= Cout are never stored)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wcol[nt] = min(cout_l + nt * 32, Cout - 1) * 4;
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    const int CK = P.CK;                       // power of two in {4, 8, 16, 32}; divides Cin
+    const int lvpp = 31 - __clz(CK) - 2;       // log2(CK / 4)
+    const int npix = (1 << lTI) * HH * HWd;
+    const int total_vec = npix << lvpp;
+    const int KG = C4 ? 1 : (CK >> 3);         // 8-channel k-groups per tap inside one chunk
+    const int nj = C4 ? ((ntaps + 1) >> 1) : ntaps * KG;
+
+    for (int cb = 0; cb < Cin; cb += CK) {
+        __syncthreads();   // all waves are done reading the previous chunk
+        for (int idx = threadIdx.x; idx < total_vec; idx += 256) {
+            const int v = idx & ((1 << lvpp) - 1);
+            const unsigned hp = (unsigned)idx >> lvpp;
+            const unsigned t = bpb_fdiv(hp, HWd, P.magic_hw);
+            const int hc = hp - t * HWd;
+            const unsigned ti = bpb_fdiv(t, HH, P.magic_hh);
+            const int hr = t - ti * HH;
+            const int n = n0 + (int)ti, ih = a0 * sa + hr + P.ih0, iw = b0 * sa + hc + P.iw0;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (n < P.N && (unsigned)ih < (unsigned)P.Hi && (unsigned)iw < (unsigned)P.Wi)
+                val = BPB_GLD4(gx + (((size_t)n * P.Hi + ih) * P.Wi + iw) * Cin + cb + v * 4);
+            *(f32x4*)(smem + hp * LD + v * 4) = val;
+        }
+        __syncthreads();
+
+        // scalar iteration state over (tap row i, tap col jj, k-group kg); no table, no memory access
+        int it_i = 0, it_j = 0, it_kg = 0, it_c4 = 0;
+        auto fetch = [&](f32x4 (&a)[2], f32x4 (&b)[NT]) {
+            int ldsoff, wq;
+            bool bvalid = true;
+            if (C4) {   // Cin == 4: lanes 0-31 take tap 2j, lanes 32-63 tap 2j+1 (phantom tap -> zero weights)
+                int t = 2 * it_c4 + half;
+                if (t >= ntaps) { t = 2 * it_c4; bvalid = false; }
+                const int ti_ = t / St, tj_ = t - ti_ * St;
+                ldsoff = (((P.dh0 + P.dhs * ti_) * HWd + (P.dw0 + P.dws * tj_)) * LD) * 4;
+                wq = (P.w0 + P.wrs * ti_ + P.wss * tj_) * cin4;
+                ++it_c4;
+            } else {
+                ldsoff = (((P.dh0 + P.dhs * it_i) * HWd + (P.dw0 + P.dws * it_j)) * LD + it_kg * 8) * 4;
+                wq = (P.w0 + P.wrs * it_i + P.wss * it_j) * cin4 + (cb >> 2) + it_kg * 2 + half;
+                if (++it_kg == KG) {
+                    it_kg = 0;
+                    if (++it_j == St) { it_j = 0; ++it_i; }
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) a[mt] = *(const f32x4*)((const char*)smem + pixoff[mt] + ldsoff);
+            const bpb_gcf wp = gw + (size_t)wq * Cout * 4;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 bv = BPB_GLD4(wp + wcol[nt]);
+                if (C4 && !bvalid) bv = f32x4{0.f, 0.f, 0.f, 0.f};
+                b[nt] = bv;
+            }
+        };
+        auto mma = [&](const f32x4 (&a)[2], const f32x4 (&b)[NT]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA32(a[mt][i], b[nt][i], acc[mt][nt]);
+        };
+        // ping-pong operand sets: the loads of k-group j+1 are in flight while the 8*NT MFMAs of k-group j run
+        f32x4 a0[2], b0[NT], a1[2], b1[NT];
+        if (nj > 0) fetch(a0, b0);   // nj == 0: empty tap set (a parity class of a strided 1x1 dgrad) -> zeros
+        for (int j = 0; j < nj; j += 2) {
+            if (j + 1 < nj) fetch(a1, b1);
+            mma(a0, b0);
+            if (j + 1 < nj) {
+                if (j + 2 < nj) fetch(a0, b0);
+                mma(a1, b1);
+            }
+        }
+    }
+
+    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bpb_gf gy = (bpb_gf)P.y;
+    const bpb_gcf gbias = (bpb_gcf)P.bias;
+    double ssum[NT], ssq[NT];
+    float bias_v[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        ssum[nt] = 0.0;
+        ssq[nt] = 0.0;
+        bias_v[nt] = (gbias && cout_l + nt * 32 < Cout) ? gbias[cout_l + nt * 32] : 0.f;
+    }
+    const bool accum = P.accumulate != 0;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int m = wave * 64 + mt * 32 + row;
+            const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
+            const int n = n0 + ti, a = a0 + th, b = b0 + tw;
+            const bool pv = (n < P.N) && (a < P.A) && (b < P.B);
+            const size_t obase = (((size_t)n * P.Ho + (a * P.osh + P.ooh)) * P.Wo + (b * P.osw + P.oow)) * Cout;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int co = cout_l + nt * 32;
+                if (pv && co < Cout) {
+                    float v = acc[mt][nt][r] + bias_v[nt];
+                    if (accum) v += gy[obase + co];
+                    gy[obase + co] = v;
+                    ssum[nt] += (double)v;
+                    ssq[nt] += (double)v * (double)v;
+                }
+            }
+        }
+    }
+    if (P.stats) {   // per-tile BatchNorm partials, combined in fp64 (deterministic: no atomics)
+        __syncthreads();
+        double* red = (double*)smem;   // [wave][NT*32][2]
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            double s = ssum[nt] + __shfl_xor(ssum[nt], 32);
+            double q = ssq[nt] + __shfl_xor(ssq[nt], 32);
+            if (half == 0) {
+                red[((wave * NT + nt) * 32 + l31) * 2 + 0] = s;
+                red[((wave * NT + nt) * 32 + l31) * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < NT * 32) {
+            const int nt = threadIdx.x >> 5, c = threadIdx.x & 31;
+            const int co = ntile * NT * 32 + nt * 32 + c;
+            if (co < Cout) {
+                double s = 0.0, q = 0.0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    s += red[((w * NT + nt) * 32 + c) * 2 + 0];
+                    q += red[((w * NT + nt) * 32 + c) * 2 + 1];
+                }
+                double BPB_GLOBAL* gs = (double BPB_GLOBAL*)P.stats;
+                gs[((size_t)mtile * 2 + 0) * Cout + co] = s;
+                gs[((size_t)mtile * 2 + 1) * Cout + co] = q;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Weight gradient:  dW[t][ci][co] = sum_{n,a,b} x[n, a*sa+dh_t+ih0, b*sa+dw_t+iw0, ci] * dy[n,a,b,co]
+// GEMM view: M = ci (32-row tile), N = co (32*NTW), K = pixels.  NHWC makes both fragments
+// "K-major with unit-stride M/N": lane l supplies x[pixel k(l>>5)][ci = l&31] and dy[pixel][co = l&31]
+// -- one conflict-free ds_read_b32 each, the dy fragment shared by all taps.
+// One workgroup owns (tap group <= 9, ci tile, co tile, a range of 128-pixel tiles); its 4 waves split
+// the pixels, accumulate in registers over the whole range, reduce through LDS and write ONE
+// partial slab; bpb_wgrad_reduce_kernel sums the slabs in a fixed order (deterministic) into OIHW.
+// ---------------------------------------------------------------------------------------
+struct BpbWgradProb {
+    const float* x;        // NHWC input of the conv
+    const float* dy;       // NHWC grad of the conv output [N][A][B][Cout]
+    float* ws;             // partial slabs [nsplit][T][Cin][Cout]
+    int N, Hi, Wi, Cin;
+    int A, B, Cout;
+    int sa, ih0, iw0;
+    int T, S;              // total taps (R*S) and filter width; tap t reads input offset (t / S, t % S)
+    int lTI, lTH, lTW;     // 128-pixel tile factorisation
+    int HH, HW, LD;
+    int tiles_a, tiles_b, n_mtiles;
+    int n_citiles, n_cotiles, n_tapgroups, nsplit;
+    int blk_begin;
+    unsigned magic_hw, magic_hh;
+};
+
+template <int TG, int NTW>   // TG = taps per group (9 for spatial filters, 1 for 1x1), NTW = 32-wide co sub-tiles
+__global__ __launch_bounds__(256) void bpb_conv_wgrad_kernel(const BpbWgradProb* __restrict__ probs, int nprobs)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int bid = blockIdx.x;
+    int pi = 0;
+    for (int i = 1; i < nprobs; ++i)
+        if (bid >= probs[i].blk_begin) pi = i;
+    const BpbWgradProb P = probs[pi];
+    bid -= P.blk_begin;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    // block id -> (split, tap group, ci tile, co tile); co fastest so neighbours share the x halo in L2
+    const int cot = bid % P.n_cotiles;
+    int r1 = bid / P.n_cotiles;
+    const int cit = r1 % P.n_citiles;
+    r1 /= P.n_citiles;
+    const int tg = r1 % P.n_tapgroups;
+    const int split = r1 / P.n_tapgroups;
+    const int t0 = tg * TG;
+    const int nt_here = min(TG, P.T - t0);
+    const int Cin = P.Cin, Cout = P.Cout;
+    const int ci0 = cit * 32, co0 = cot * 32 * NTW;
+    const int ckc = min(32, Cin - ci0);            // valid input channels in this tile (multiple of 4)
+    const int LD = P.LD, HWd = P.HW, HH = P.HH, sa = P.sa;
+    const int lTW = P.lTW, lTH = P.lTH, lTI = P.lTI;
+    const int TWm = (1 << lTW) - 1, THm = (1 << lTH) - 1;
+    const int npix_h = (1 << lTI) * HH * HWd;
+    constexpr int LDY = 32 * NTW;
+    float* sx = smem;                                // halo [npix_h][LD]
+    float* sdy = smem + ((npix_h * LD + 3) & ~3);    // dy tile [128][LDY]
+
+    f32x16 acc[TG][NTW];
+#pragma unroll
+    for (int t = 0; t < TG; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][nt][r] = 0.f;
+
+    int tapoff[TG];
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+        const int tt = min(t0 + t, P.T - 1);
+        tapoff[t] = (((tt / P.S) * HWd + (tt % P.S)) * LD) * 4;
+    }
+
+    // M-tile range of this split
+    const int per = (P.n_mtiles + P.nsplit - 1) / P.nsplit;
+    const int mt_begin = split * per, mt_end = min(P.n_mtiles, mt_begin + per);
+    const int vpp = 8;   // float4 per halo pixel (32 channels; channels >= ckc are zero-filled)
+
+    for (int mtile = mt_begin; mtile < mt_end; ++mtile) {
+        const int tb = mtile % P.tiles_b, t2 = mtile / P.tiles_b;
+        const int ta = t2 % P.tiles_a, tn = t2 / P.tiles_a;
+        const int n0 = tn << lTI, a0 = ta << lTH, b0 = tb << lTW;
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < npix_h * vpp; idx += 256) {
+            const int v = idx & 7;
+            const unsigned hp = (unsigned)idx >> 3;
+            const unsigned t = bpb_fdiv(hp, HWd, P.magic_hw);
+            const int hc = hp - t * HWd;
+            const unsigned ti = bpb_fdiv(t, HH, P.magic_hh);
+            const int hr = t - ti * HH;
+            const int n = n0 + (int)ti, ih = a0 * sa + hr + P.ih0, iw = b0 * sa + hc + P.iw0;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (v * 4 < ckc && n < P.N && (unsigned)ih < (unsigned)P.Hi && (unsigned)iw < (unsigned)P.Wi)
+                val = BPB_GLD4((bpb_gcf)P.x + (((size_t)n * P.Hi + ih) * P.Wi + iw) * Cin + ci0 + v * 4);
+            *(f32x4*)(sx + hp * LD + v * 4) = val;
+        }
+        for (int idx = threadIdx.x; idx < 128 * (LDY / 4); idx += 256) {
+            const int v = idx % (LDY / 4), m = idx / (LDY / 4);
+            const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
+            const int n = n0 + ti, a = a0 + th, b = b0 + tw;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            const int co = co0 + v * 4;
+            if (n < P.N && a < P.A && b < P.B && co < Cout)   // Cout % 4 == 0
+                val = BPB_GLD4((bpb_gcf)P.dy + (((size_t)n * P.A + a) * P.B + b) * Cout + co);
+            *(f32x4*)(sdy + m * LDY + v * 4) = val;
+        }
+        __syncthreads();
+        // wave handles pixels [wave*32, wave*32+32): 16 k-steps of 2 pixels
+#pragma unroll 4
+        for (int ks = 0; ks < 16; ++ks) {
+            const int m = wave * 32 + ks * 2 + half;
+            const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
+            const int xo = (((ti * HH + th * sa) * HWd + tw * sa) * LD + l31) * 4;
+            float bfrag[NTW];
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) bfrag[nt] = sdy[m * LDY + nt * 32 + l31];
+#pragma unroll
+            for (int t = 0; t < TG; ++t) {
+                if (t < nt_here) {
+                    const float afrag = *(const float*)((const char*)sx + xo + tapoff[t]);
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) acc[t][nt] = MFMA32(afrag, bfrag[nt], acc[t][nt]);
+                }
+            }
+        }
+    }
+
+    // cross-wave reduction through LDS, one tap at a time; row = ci, col = co
+    float* red = smem;   // [4 waves][16 regs][64 lanes]
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+        if (t < nt_here) {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[t][nt][r];
+                __syncthreads();
+                // 1024 values, 256 threads -> 4 each: (reg, lane) pairs
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int idx = e * 256 + threadIdx.x;
+                    const int r = idx >> 6, ln = idx & 63;
+                    const float s = red[(0 * 16 + r) * 64 + ln] + red[(1 * 16 + r) * 64 + ln] +
+                                    red[(2 * 16 + r) * 64 + ln] + red[(3 * 16 + r) * 64 + ln];
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+                    const int ci = ci0 + row, co = co0 + nt * 32 + (ln & 31);
+                    if (ci < Cin && co < Cout)
+                        ((bpb_gf)P.ws)[(((size_t)split * P.T + (t0 + t)) * Cin + ci) * Cout + co] = s;
+                }
+            }
+        }
+    }
+}
+
+// dW[co][ci_real][t] (OIHW, the state-dict layout) (+)= sum_split ws[split][t][ci][co]
+__global__ void bpb_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int T,
+                                        int Cin, int Cin_real, int Cout, int accumulate)
+{
+    const long total = (long)T * Cin_real * Cout;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cout);
+        const long r = i / Cout;
+        const int ci = (int)(r % Cin_real), t = (int)(r / Cin_real);
+        float s = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) s += ws[(((size_t)sp * T + t) * Cin + ci) * Cout + co];
+        const size_t o = ((size_t)co * Cin_real + ci) * T + t;
+        dw[o] = accumulate ? dw[o] + s : s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Weight packing, one launch for every conv of a network (descriptor table):
+//   fwd   wf[t][ci/4][co][4]  = W[co][ci][t]            (ci zero-padded to Cin_pad)
+//   dgrad wd[t][co/4][ci][4]  = W[co][ci][t]            (only when wd != nullptr)
+// ---------------------------------------------------------------------------------------
+struct BpbPackProb {
+    const float* w;   // OIHW
+    float* wf;
+    float* wd;
+    int Cout, Cin, Cin_pad, T;
+    int blk_begin;
+};
+
+__global__ void bpb_pack_weights_kernel(const BpbPackProb* __restrict__ probs, int nprobs)
+{
+    int bid = blockIdx.x;
+    int lo = 0, hi = nprobs - 1;   // binary search over blk_begin (hundreds of convs)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (probs[mid].blk_begin <= bid) lo = mid; else hi = mid - 1;
+    }
+    const BpbPackProb& P = probs[lo];
+    bid -= P.blk_begin;
+    const long i = (long)bid * blockDim.x + threadIdx.x;
+    const long nf = (long)P.T * P.Cin_pad * P.Cout;
+    if (i < nf) {   // i enumerates wf linearly: [t][q][co][e]
+        const int e = (int)(i & 3);
+        long r = i >> 2;
+        const int co = (int)(r % P.Cout);
+        r /= P.Cout;
+        const int q = (int)(r % (P.Cin_pad >> 2)), t = (int)(r / (P.Cin_pad >> 2));
+        const int ci = q * 4 + e;
+        P.wf[i] = ci < P.Cin ? P.w[((size_t)co * P.Cin + ci) * P.T + t] : 0.f;
+    }
+    if (P.wd) {
+        const long nd = (long)P.T * P.Cout * P.Cin_pad;
+        if (i < nd) {   // [t][co/4][ci][e]
+            const int e = (int)(i & 3);
+            long r = i >> 2;
+            const int ci = (int)(r % P.Cin_pad);
+            r /= P.Cin_pad;
+            const int q = (int)(r % (P.Cout >> 2)), t = (int)(r / (P.Cout >> 2));
+            const int co = q * 4 + e;
+            P.wd[i] = ci < P.Cin ? P.w[((size_t)co * P.Cin + ci) * P.T + t] : 0.f;
+        }
+    }
+}
+
+// ------------------------------------ C ABI ------------------------------------------
+static int conv_lds_bytes(const BpbConvProb& p)
+{
+    const int npix = (1 << p.lTI) * p.HH * p.HW;
+    int b = npix * p.LD * 4;
+    return b < 8192 ? 8192 : b;
+}
+
+extern "C" {
+
+// One-time per-process setup: allow the conv kernels to use up to 160 KiB of dynamic LDS.
+int bpb_conv_init(void)
+{
+#define BPB_ATTR(K)                                                                                          \
+    {                                                                                                        \
+        hipError_t e = hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        if (e != hipSuccess) return bpb_set_error((int)e, "bpb_conv_init: %s", hipGetErrorString(e));            \
+    }
+    BPB_ATTR((bpb_conv_igemm_kernel<1, false>))
+    BPB_ATTR((bpb_conv_igemm_kernel<2, false>))
+    BPB_ATTR((bpb_conv_igemm_kernel<1, true>))
+    BPB_ATTR((bpb_conv_igemm_kernel<2, true>))
+    BPB_ATTR((bpb_conv_wgrad_kernel<1, 1>))
+    BPB_ATTR((bpb_conv_wgrad_kernel<9, 1>))
+    BPB_ATTR((bpb_conv_wgrad_kernel<1, 2>))
+    BPB_ATTR((bpb_conv_wgrad_kernel<1, 4>))
+#undef BPB_ATTR
+    return 0;
+}
+
+// Launch a group of conv problems (descriptors already in device memory, `h_probs` is the host copy
+// used for validation and grid sizing).  Replaces aten::conv2d / conv backward-input on the path.
+int bpb_conv_igemm(const BpbConvProb* d_probs, const BpbConvProb* h_probs, int nprobs, hipStream_t stream)
+{
+    BPB_REQUIRE(nprobs >= 1 && nprobs <= 16, "bpb_conv_igemm: nprobs=%d out of range", nprobs);
+    int nblk = 0, lds = 0, nt = 0;
+    const bool c4 = h_probs[0].Cin == 4;
+    for (int i = 0; i < nprobs; ++i) {
+        const BpbConvProb& p = h_probs[i];
+        BPB_REQUIRE(p.Cin == 4 || p.Cin % 8 == 0, "bpb_conv_igemm: Cin=%d must be 4 or a multiple of 8", p.Cin);
+        BPB_REQUIRE(p.CK >= 4 && p.CK <= 32 && (p.CK & (p.CK - 1)) == 0 && p.Cin % p.CK == 0 && (p.Cin == 4 || p.CK >= 8),
+                    "bpb_conv_igemm: bad channel chunk CK=%d for Cin=%d", p.CK, p.Cin);
+        BPB_REQUIRE(p.LD >= p.CK && p.LD % 4 == 0, "bpb_conv_igemm: bad LDS pitch %d", p.LD);
+        BPB_REQUIRE(p.lTI + p.lTH + p.lTW == 8, "bpb_conv_igemm: M tile must be 256 pixels");
+        BPB_REQUIRE(p.Rt >= 0 && p.St >= 0 && p.Rt * p.St <= 64, "bpb_conv_igemm: tap grid %dx%d", p.Rt, p.St);
+        BPB_REQUIRE(i == 0 || (p.Cin == 4) == (h_probs[0].Cin == 4), "bpb_conv_igemm: Cin==4 problems need their own group");
+        BPB_REQUIRE(p.blk_begin == nblk, "bpb_conv_igemm: blk_begin mismatch");
+        BPB_REQUIRE(((uintptr_t)p.x & 15) == 0 && ((uintptr_t)p.w & 15) == 0, "bpb_conv_igemm: x/w must be 16-byte aligned");
+        const int this_nt = p.Cout <= 32 ? 1 : 2;
+        BPB_REQUIRE(nt == 0 || nt == this_nt, "bpb_conv_igemm: mixed N-tile widths in one group");
+        nt = this_nt;
+        BPB_REQUIRE(p.n_ntiles == bpb_cdiv(p.Cout, 32 * nt), "bpb_conv_igemm: n_ntiles mismatch");
+        nblk += p.n_mtiles * p.n_ntiles;
+        const int l = conv_lds_bytes(p);
+        lds = l > lds ? l : lds;
+    }
+    BPB_REQUIRE(lds <= 160 * 1024, "bpb_conv_igemm: halo tile needs %d B of LDS", lds);
+    if (nblk == 0) return 0;
+#define BPB_CONV_LAUNCH(NT, C4) \
+    hipLaunchKernelGGL((bpb_conv_igemm_kernel<NT, C4>), dim3(nblk), dim3(256), lds, stream, d_probs, nprobs)
+    if (c4 && nt == 1) { BPB_CONV_LAUNCH(1, true); }
+    else if (c4) { BPB_CONV_LAUNCH(2, true); }
+    else if (nt == 1) { BPB_CONV_LAUNCH(1, false); }
+    else { BPB_CONV_LAUNCH(2, false); }
+#undef BPB_CONV_LAUNCH
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_conv_wgrad(const BpbWgradProb* d_probs, const BpbWgradProb* h_probs, int nprobs, hipStream_t stream)
+{
+    BPB_REQUIRE(nprobs >= 1 && nprobs <= 16, "bpb_conv_wgrad: nprobs=%d out of range", nprobs);
+    int nblk = 0, lds = 0, ntw = 0;
+    for (int i = 0; i < nprobs; ++i) {
+        const BpbWgradProb& p = h_probs[i];
+        BPB_REQUIRE(p.Cin % 4 == 0 && p.Cout % 4 == 0, "bpb_conv_wgrad: Cin/Cout must be multiples of 4");
+        BPB_REQUIRE(p.lTI + p.lTH + p.lTW == 7, "bpb_conv_wgrad: M tile must be 128 pixels");
+        BPB_REQUIRE(p.LD >= 32 && p.LD % 4 == 0, "bpb_conv_wgrad: bad LDS pitch");
+        BPB_REQUIRE(p.T >= 1 && p.S >= 1 && p.T % p.S == 0, "bpb_conv_wgrad: T=%d S=%d", p.T, p.S);
+        BPB_REQUIRE(p.blk_begin == nblk, "bpb_conv_wgrad: blk_begin mismatch");
+        const int this_ntw = (p.T == 1 && p.Cout >= 128) ? 4 : (p.T == 1 && p.Cout >= 64) ? 2 : 1;
+        BPB_REQUIRE(ntw == 0 || ntw == this_ntw, "bpb_conv_wgrad: mixed tile widths in one group");
+        BPB_REQUIRE(i == 0 || (p.T == 1) == (h_probs[0].T == 1), "bpb_conv_wgrad: 1x1 and spatial filters cannot share a group");
+        ntw = this_ntw;
+        BPB_REQUIRE(p.n_cotiles == bpb_cdiv(p.Cout, 32 * ntw) && p.n_citiles == bpb_cdiv(p.Cin, 32) &&
+                    p.n_tapgroups == (p.T == 1 ? 1 : bpb_cdiv(p.T, 9)), "bpb_conv_wgrad: tile counts mismatch");
+        nblk += p.nsplit * p.n_tapgroups * p.n_citiles * p.n_cotiles;
+        const int npix = (1 << p.lTI) * p.HH * p.HW;
+        int l = ((npix * p.LD + 3) & ~3) * 4 + 128 * 32 * ntw * 4;
+        if (l < 16384) l = 16384;
+        lds = l > lds ? l : lds;
+    }
+    BPB_REQUIRE(lds <= 160 * 1024, "bpb_conv_wgrad: needs %d B of LDS", lds);
+    if (nblk == 0) return 0;
+#define BPB_WG_LAUNCH(TG, NTW) \
+    hipLaunchKernelGGL((bpb_conv_wgrad_kernel<TG, NTW>), dim3(nblk), dim3(256), lds, stream, d_probs, nprobs)
+    if (ntw == 1 && h_probs[0].T == 1) { BPB_WG_LAUNCH(1, 1); }
+    else if (ntw == 1) { BPB_WG_LAUNCH(9, 1); }
+    else if (ntw == 2) { BPB_WG_LAUNCH(1, 2); }
+    else { BPB_WG_LAUNCH(1, 4); }
+#undef BPB_WG_LAUNCH
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_wgrad_reduce(const float* ws, float* dw, int nsplit, int T, int Cin, int Cin_real, int Cout, int accumulate,
+                     hipStream_t stream)
+{
+    const long total = (long)T * Cin_real * Cout;
+    BPB_REQUIRE(total > 0 && nsplit >= 1, "bpb_wgrad_reduce: empty problem");
+    int grid = bpb_cdiv(total, 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(bpb_wgrad_reduce_kernel, dim3(grid), dim3(256), 0, stream, ws, dw, nsplit, T, Cin, Cin_real, Cout,
+                       accumulate);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_pack_weights(const BpbPackProb* d_probs, int nprobs, int total_blocks, hipStream_t stream)
+{
+    BPB_REQUIRE(nprobs >= 1 && total_blocks >= 1, "bpb_pack_weights: empty");
+    hipLaunchKernelGGL(bpb_pack_weights_kernel, dim3(total_blocks), dim3(256), 0, stream, d_probs, nprobs);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+}   // extern "C"

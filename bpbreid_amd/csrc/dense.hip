@@ -1,0 +1,214 @@
+// Small dense layers after pooling: Linear (fwd, dX, dW) on the fp32 MFMA pipe and BatchNorm1d (+ReLU).
+//
+// Replaces torchreid/models/bpbreid.py:324-350 (AfterPoolingDimReduceLayer: Linear(C->D,bias)+BN1d+ReLU),
+// :398-415 (BNClassifier: BN1d with frozen bias -> Linear(D->classes, no bias)) and :261-279 (per-part
+// classifiers).  These GEMMs are skinny (M = N or N*K rows = 64..320, K up to 2560): one generic strided
+// kernel C = A(MxK) . B(KxN) with split-K so that more than a handful of CUs participate; the slabs are
+// summed in a fixed order (deterministic) by the reduce kernel, which also adds the bias.
+#include "bpb_common.h"
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// C_part[split][M][N] = sum_{k in split} A[m*sam + k*sak] * B[k*sbk + n*sbn]
+// block = 256 threads = 2x2 waves, block tile 64x64, k-step 16, LDS tiles stored k-major ([k][64+pad]).
+__global__ __launch_bounds__(256) void bpb_gemm_kernel(const float* __restrict__ A, long sam, long sak,
+                                                       const float* __restrict__ B, long sbk, long sbn,
+                                                       float* __restrict__ Cpart, int M, int N, int K, int kchunk)
+{
+    __shared__ float As[16][68];
+    __shared__ float Bs[16][68];
+    const int tiles_n = (N + 63) >> 6;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int split = blockIdx.y;
+    const int k_begin = split * kchunk, k_end = min(K, k_begin + kchunk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const bool a_kfast = (sak == 1), b_kfast = (sbk == 1);
+    for (int k0 = k_begin; k0 < k_end; k0 += 16) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int m, k;
+            if (a_kfast) { k = threadIdx.x & 15; m = (threadIdx.x >> 4) + 16 * i; }
+            else { m = threadIdx.x & 63; k = (threadIdx.x >> 6) + 4 * i; }
+            const int gm = tm * 64 + m, gk = k0 + k;
+            As[k][m] = (gm < M && gk < k_end) ? A[gm * sam + gk * sak] : 0.f;
+            int n, kb;
+            if (b_kfast) { kb = threadIdx.x & 15; n = (threadIdx.x >> 4) + 16 * i; }
+            else { n = threadIdx.x & 63; kb = (threadIdx.x >> 6) + 4 * i; }
+            const int gn = tn * 64 + n, gkb = k0 + kb;
+            Bs[kb][n] = (gn < N && gkb < k_end) ? B[gkb * sbk + gn * sbn] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2) acc = MFMA32(As[kk + half][wm + l31], Bs[kk + half][wn + l31], acc);
+    }
+    float* Cp = Cpart + (long)split * M * N;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = tm * 64 + wm + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int col = tn * 64 + wn + l31;
+        if (row < M && col < N) Cp[(long)row * N + col] = acc[r];
+    }
+}
+
+// C[m*ldc + n] (+)= sum_s part[s][m][n] + bias[n]
+__global__ __launch_bounds__(256) void bpb_gemm_reduce_kernel(const float* __restrict__ part, int nsplit, float* __restrict__ C,
+                                                              long ldc, const float* __restrict__ bias, int M, int N,
+                                                              int accumulate)
+{
+    const long total = (long)M * N;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+        const int n = (int)(i % N);
+        const long m = i / N;
+        float s = bias ? bias[n] : 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) s += part[(long)sp * total + i];
+        float* o = C + m * ldc + n;
+        *o = accumulate ? *o + s : s;
+    }
+}
+
+// column sums: out[n] (+)= sum_m X[m][n]   (bias gradient of Linear)
+__global__ __launch_bounds__(256) void bpb_colsum_kernel(const float* __restrict__ X, float* __restrict__ out, int M, int N,
+                                                         int accumulate)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n < N) {
+        float s = 0.f;
+        for (int m = 0; m < M; ++m) s += X[(long)m * N + n];
+        out[n] = accumulate ? out[n] + s : s;
+    }
+}
+
+// ---- BatchNorm1d over rows, fused optional ReLU -------------------------------------------------
+// training: batch statistics (biased var for normalisation, unbiased for running_var), saves mean/invstd.
+// x rows have stride ldx (so that a [N][K][D] tensor can be normalised per part column-block).
+__global__ __launch_bounds__(256) void bpb_bn1d_fwd_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y,
+                                                           long ldy, int R, int F, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var, float* __restrict__ save_mean,
+                                                           float* __restrict__ save_invstd, float eps, float momentum,
+                                                           int training, int relu)
+{
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= F) return;
+    float mean, invstd;
+    if (training) {
+        double s = 0.0, q = 0.0;
+        for (int r = 0; r < R; ++r) {
+            const double v = (double)x[r * ldx + f];
+            s += v;
+            q += v * v;
+        }
+        const double mu = s / R;
+        double var = q / R - mu * mu;
+        if (var < 0.0) var = 0.0;
+        mean = (float)mu;
+        invstd = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) {
+            const double unbiased = R > 1 ? var * R / (R - 1.0) : var;
+            running_mean[f] = (1.f - momentum) * running_mean[f] + momentum * mean;
+            running_var[f] = (1.f - momentum) * running_var[f] + momentum * (float)unbiased;
+        }
+        if (save_mean) { save_mean[f] = mean; save_invstd[f] = invstd; }
+    } else {
+        mean = running_mean[f];
+        invstd = 1.f / sqrtf(running_var[f] + eps);
+    }
+    const float g = gamma ? gamma[f] : 1.f, b = beta ? beta[f] : 0.f;
+    for (int r = 0; r < R; ++r) {
+        float v = (x[r * ldx + f] - mean) * invstd * g + b;
+        if (relu && v < 0.f) v = 0.f;
+        y[r * ldy + f] = v;
+    }
+}
+
+// backward (training statistics): dx = g*invstd/R * (R*dy - sum dy - xhat * sum(dy*xhat)); ReLU mask from y.
+__global__ __launch_bounds__(256) void bpb_bn1d_bwd_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ x,
+                                                           long ldx, const float* __restrict__ y, long ldy,
+                                                           float* __restrict__ dx, long lddx, int R, int F,
+                                                           const float* __restrict__ gamma, const float* __restrict__ save_mean,
+                                                           const float* __restrict__ save_invstd, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int relu, int accumulate_params)
+{
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= F) return;
+    const float mean = save_mean[f], invstd = save_invstd[f];
+    const float g = gamma ? gamma[f] : 1.f;
+    double s = 0.0, q = 0.0;
+    for (int r = 0; r < R; ++r) {
+        float d = dy[r * lddy + f];
+        if (relu && !(y[r * ldy + f] > 0.f)) d = 0.f;
+        const float xh = (x[r * ldx + f] - mean) * invstd;
+        s += (double)d;
+        q += (double)d * (double)xh;
+    }
+    if (dgamma) dgamma[f] = accumulate_params ? dgamma[f] + (float)q : (float)q;
+    if (dbeta) dbeta[f] = accumulate_params ? dbeta[f] + (float)s : (float)s;
+    const float k1 = (float)(s / R), k2 = (float)(q / R);
+    for (int r = 0; r < R; ++r) {
+        float d = dy[r * lddy + f];
+        if (relu && !(y[r * ldy + f] > 0.f)) d = 0.f;
+        const float xh = (x[r * ldx + f] - mean) * invstd;
+        dx[r * lddx + f] = g * invstd * (d - k1 - xh * k2);
+    }
+}
+
+extern "C" {
+
+// workspace: nsplit*M*N floats.  Returns the split count it wants through *nsplit_out when ws == nullptr.
+int bpb_gemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc, const float* bias,
+             int M, int N, int K, int accumulate, float* ws, int* nsplit_out, hipStream_t stream)
+{
+    BPB_REQUIRE(M >= 1 && N >= 1 && K >= 1, "bpb_gemm: bad sizes %d %d %d", M, N, K);
+    const int tiles = bpb_cdiv(M, 64) * bpb_cdiv(N, 64);
+    int nsplit = 1;
+    while (nsplit < 16 && tiles * nsplit < 256 && K / (nsplit * 2) >= 128) nsplit *= 2;
+    if (nsplit_out) *nsplit_out = nsplit;
+    if (!ws) return 0;
+    int kchunk = bpb_cdiv(K, nsplit);
+    kchunk = (kchunk + 15) & ~15;
+    hipLaunchKernelGGL(bpb_gemm_kernel, dim3(tiles, nsplit), dim3(256), 0, stream, A, sam, sak, B, sbk, sbn, ws, M, N, K,
+                       kchunk);
+    long g = ((long)M * N + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(bpb_gemm_reduce_kernel, dim3((int)g), dim3(256), 0, stream, ws, nsplit, C, ldc, bias, M, N, accumulate);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_colsum(const float* X, float* out, int M, int N, int accumulate, hipStream_t stream)
+{
+    hipLaunchKernelGGL(bpb_colsum_kernel, dim3(bpb_cdiv(N, 256)), dim3(256), 0, stream, X, out, M, N, accumulate);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_bn1d_fwd(const float* x, long ldx, float* y, long ldy, int R, int F, const float* gamma, const float* beta,
+                 float* running_mean, float* running_var, float* save_mean, float* save_invstd, float eps, float momentum,
+                 int training, int relu, hipStream_t stream)
+{
+    BPB_REQUIRE(R >= 1 && F >= 1, "bpb_bn1d_fwd: bad sizes");
+    BPB_REQUIRE(training || (running_mean && running_var), "bpb_bn1d_fwd: eval mode needs running statistics");
+    hipLaunchKernelGGL(bpb_bn1d_fwd_kernel, dim3(bpb_cdiv(F, 256)), dim3(256), 0, stream, x, ldx, y, ldy, R, F, gamma, beta,
+                       running_mean, running_var, save_mean, save_invstd, eps, momentum, training, relu);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_bn1d_bwd(const float* dy, long lddy, const float* x, long ldx, const float* y, long ldy, float* dx, long lddx, int R,
+                 int F, const float* gamma, const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
+                 int relu, int accumulate_params, hipStream_t stream)
+{
+    BPB_REQUIRE(R >= 1 && F >= 1, "bpb_bn1d_bwd: bad sizes");
+    hipLaunchKernelGGL(bpb_bn1d_bwd_kernel, dim3(bpb_cdiv(F, 256)), dim3(256), 0, stream, dy, lddy, x, ldx, y, ldy, dx, lddx,
+                       R, F, gamma, save_mean, save_invstd, dgamma, dbeta, relu, accumulate_params);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+}   // extern "C"

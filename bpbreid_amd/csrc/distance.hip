@@ -1,0 +1,152 @@
+// Eval-time part-based query x gallery distance with visibility-masked combination.
+//
+// Replaces torchreid/metrics/distance.py:87-247: per-part Euclidean (no epsilon, relu + sqrt, :230-236) or
+// cosine distance [P,Q,G], pair mask q_vis[p,q] * g_vis[p,g] (sqrt for continuous scores, :199), masked mean /
+// max over parts with -1 for pairs without a common visible part, then -1 -> max+1 (:171-176, :214-216).
+// The reference loops over gallery chunks of 500 with a .cpu() per chunk; here one launch covers a gallery
+// shard: a 64x64 (query, gallery) tile runs the P batched GEMMs back to back on the fp32 MFMA pipe and
+// folds each part's distance straight into the masked sums in registers.
+#include "bpb_common.h"
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// sq[r][p] = sum_d f[r][p][d]^2
+__global__ __launch_bounds__(256) void bpb_rownorm_kernel(const float* __restrict__ f, float* __restrict__ sq, long rows, int D)
+{
+    const long r = blockIdx.x * 4L + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) { const float v = f[r * D + d]; s = fmaf(v, v, s); }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) sq[r] = s;
+}
+
+// mode: 0 no visibility, 1 boolean visibility (vis values 0/1), 2 continuous visibility.  strat: 0 mean, 1 max.
+// parts_out[p][q][g] : per-part distance (mode 1: -1 where the pair mask is 0); dist_out[q][g]: combined (-1 invalid).
+// maxbits: atomicMax over the int bit pattern of every non-negative value written to parts_out (max+1 fill).
+__global__ __launch_bounds__(256) void bpb_part_distance_kernel(const float* __restrict__ qf, const float* __restrict__ gf,
+                                                                const float* __restrict__ qsq, const float* __restrict__ gsq,
+                                                                const float* __restrict__ qvis, const float* __restrict__ gvis,
+                                                                int Q, int G, int P, int D, int mode, int strat, int cosine,
+                                                                float* __restrict__ parts_out, float* __restrict__ dist_out,
+                                                                int* __restrict__ maxbits)
+{
+    __shared__ float As[16][68];
+    __shared__ float Bs[16][68];
+    const int tiles_g = (G + 63) >> 6;
+    const int tq = blockIdx.x / tiles_g, tg = blockIdx.x % tiles_g;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int g = tg * 64 + wn + l31;                 // this lane's gallery column
+    float sumv[16], sumw[16], mxv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sumv[r] = 0.f; sumw[r] = 0.f; mxv[r] = -1.f; }
+    float lmax = 0.f;
+    const long PD = (long)P * D;
+    for (int p = 0; p < P; ++p) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int k0 = 0; k0 < D; k0 += 16) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = threadIdx.x & 15, m = (threadIdx.x >> 4) + 16 * i;
+                const int gq = tq * 64 + m, gg = tg * 64 + m, gk = k0 + k;
+                As[k][m] = (gq < Q && gk < D) ? qf[gq * PD + (long)p * D + gk] : 0.f;
+                Bs[k][m] = (gg < G && gk < D) ? gf[gg * PD + (long)p * D + gk] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < 16; kk += 2) acc = MFMA32(As[kk + half][wm + l31], Bs[kk + half][wn + l31], acc);
+        }
+        const float gs = (g < G) ? gsq[(long)g * P + p] : 0.f;
+        const float gv = (mode != 0 && g < G) ? gvis[(long)g * P + p] : 1.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = tq * 64 + wm + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (q < Q && g < G) {
+                float d;
+                if (cosine) d = 1.f - acc[r];
+                else {
+                    d = qsq[(long)q * P + p] - 2.f * acc[r] + gs;
+                    d = sqrtf(d > 0.f ? d : 0.f);
+                }
+                float m = 1.f;
+                if (mode != 0) {
+                    m = qvis[(long)q * P + p] * gv;
+                    if (mode == 2) m = sqrtf(m);
+                }
+                float pv = d;
+                if (mode == 1 && m == 0.f) pv = -1.f;
+                parts_out[((long)p * Q + q) * G + g] = pv;
+                if (pv > lmax) lmax = pv;
+                sumv[r] += d * m;
+                sumw[r] += m;
+                if (m != 0.f && d > mxv[r]) mxv[r] = d;
+                if (mode == 0 && strat == 1 && d > mxv[r]) mxv[r] = d;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int q = tq * 64 + wm + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (q < Q && g < G) {
+            float v;
+            if (mode == 0) v = strat == 1 ? mxv[r] : sumv[r] / (float)P;
+            else if (mode == 1 && strat == 1) v = mxv[r];                      // stays -1 when no part is shared
+            else v = sumw[r] == 0.f ? -1.f : sumv[r] / sumw[r];                 // masked mean (mode 2 always mean)
+            dist_out[(long)q * G + g] = v;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+    if (lane == 0 && lmax > 0.f) atomicMax(maxbits, __float_as_int(lmax));
+}
+
+// -1 -> max + 1  (distance.py:171-176 for boolean masks: both matrices; :214-216 for continuous: distmat only)
+__global__ __launch_bounds__(256) void bpb_fill_invalid_kernel(float* __restrict__ x, long n, const int* __restrict__ maxbits)
+{
+    const float fillv = __int_as_float(maxbits[0]) + 1.f;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L)
+        if (x[i] == -1.f) x[i] = fillv;
+}
+
+extern "C" {
+
+// scratch: qsq [Q*P], gsq [G*P] floats, maxbits 1 int (zeroed by the callee).  vis arrays are float [rows][P].
+// finalize != 0 applies the -1 -> max+1 replacement using the maximum of THIS call; a caller that shards the
+// gallery passes finalize = 0, all-reduces (max) `maxbits` and calls bpb_part_distance_fill itself.
+int bpb_part_distance(const float* qf, const float* gf, const float* qvis, const float* gvis, int Q, int G, int P, int D,
+                      int mode, int strat, int cosine, float* qsq, float* gsq, int* maxbits, float* parts_out,
+                      float* dist_out, int finalize, hipStream_t stream)
+{
+    BPB_REQUIRE(Q >= 1 && G >= 1 && P >= 1 && D >= 1, "bpb_part_distance: bad sizes");
+    BPB_REQUIRE(mode >= 0 && mode <= 2 && (strat == 0 || strat == 1), "bpb_part_distance: bad mode/strategy");
+    BPB_REQUIRE(!(mode == 2 && strat == 1), "bpb_part_distance: continuous visibility supports 'mean' only (distance.py:200)");
+    (void)hipMemsetAsync(maxbits, 0, sizeof(int), stream);
+    hipLaunchKernelGGL(bpb_rownorm_kernel, dim3(bpb_cdiv((long)Q * P, 4)), dim3(256), 0, stream, qf, qsq, (long)Q * P, D);
+    hipLaunchKernelGGL(bpb_rownorm_kernel, dim3(bpb_cdiv((long)G * P, 4)), dim3(256), 0, stream, gf, gsq, (long)G * P, D);
+    const int tiles = bpb_cdiv(Q, 64) * bpb_cdiv(G, 64);
+    hipLaunchKernelGGL(bpb_part_distance_kernel, dim3(tiles), dim3(256), 0, stream, qf, gf, qsq, gsq, qvis, gvis, Q, G, P, D,
+                       mode, strat, cosine, parts_out, dist_out, maxbits);
+    if (finalize && mode != 0) {
+        hipLaunchKernelGGL(bpb_fill_invalid_kernel, dim3(1024), dim3(256), 0, stream, dist_out, (long)Q * G, maxbits);
+        if (mode == 1)
+            hipLaunchKernelGGL(bpb_fill_invalid_kernel, dim3(2048), dim3(256), 0, stream, parts_out, (long)P * Q * G, maxbits);
+    }
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_part_distance_fill(float* x, long n, const int* maxbits, hipStream_t stream)
+{
+    hipLaunchKernelGGL(bpb_fill_invalid_kernel, dim3(1024), dim3(256), 0, stream, x, n, maxbits);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+}   // extern "C"

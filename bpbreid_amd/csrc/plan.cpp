@@ -1,0 +1,131 @@
+// Plan executor: the backbone forward / backward is a static list of launches (shapes, buffers and
+// descriptors are fixed once the model is built for a batch shape), so the hot loop is ONE host call that
+// walks an array of ops and enqueues kernels on the given stream -- no Python, no allocator, no
+// per-launch argument marshalling.  This is the native counterpart of the reference's module-by-module
+// Python dispatch (torchreid/models/hrnet.py:532-576 runs ~650 nn.Module calls per forward).
+// The same array can be recorded into a hipGraph by capturing the stream around bpb_plan_run.
+#include "bpb_common.h"
+
+struct BpbConvProb;
+struct BpbWgradProb;
+struct BpbPackProb;
+struct BpbFuseArgs;
+struct BpbTermBwdArgs;
+struct BpbBilinearArgs;
+
+extern "C" {
+int bpb_conv_igemm(const BpbConvProb*, const BpbConvProb*, int, hipStream_t);
+int bpb_conv_wgrad(const BpbWgradProb*, const BpbWgradProb*, int, hipStream_t);
+int bpb_wgrad_reduce(const float*, float*, int, int, int, int, int, int, hipStream_t);
+int bpb_pack_weights(const BpbPackProb*, int, int, hipStream_t);
+int bpb_bn_finalize(const double*, int, int, double, const float*, const float*, float, float, float*, float*, float*,
+                    float*, float*, float*, hipStream_t);
+int bpb_bn_eval_affine(int, const float*, const float*, const float*, const float*, float, float*, float*, hipStream_t);
+int bpb_channel_stats(const float*, long, int, double*, int, hipStream_t);
+int bpb_fuse_fwd(const BpbFuseArgs*, hipStream_t);
+int bpb_term_bwd(const BpbTermBwdArgs*, int, int, hipStream_t);
+int bpb_bn_bwd_finalize(const double*, int, int, double, float*, float*, int, float*, float*, hipStream_t);
+int bpb_nchw_to_nhwc4(const float*, float*, int, int, int, int, hipStream_t);
+int bpb_maxpool3x3s2_fwd(const float*, float*, unsigned char*, int, int, int, int, hipStream_t);
+int bpb_maxpool3x3s2_bwd(const float*, const unsigned char*, float*, int, int, int, int, int, hipStream_t);
+int bpb_bilinear_concat_fwd(const BpbBilinearArgs*, hipStream_t);
+int bpb_bilinear_concat_bwd(const BpbBilinearArgs*, float*, hipStream_t);
+int bpb_fill(float*, float, long, hipStream_t);
+}
+
+enum BpbOpKind {
+    BPB_OP_CONV = 0,
+    BPB_OP_WGRAD = 1,
+    BPB_OP_WGRAD_REDUCE = 2,
+    BPB_OP_PACK = 3,
+    BPB_OP_BN_FINALIZE = 4,
+    BPB_OP_BN_EVAL_AFFINE = 5,
+    BPB_OP_FUSE_FWD = 6,
+    BPB_OP_TERM_BWD = 7,
+    BPB_OP_BN_BWD_FINALIZE = 8,
+    BPB_OP_NCHW_TO_NHWC4 = 9,
+    BPB_OP_MAXPOOL_FWD = 10,
+    BPB_OP_MAXPOOL_BWD = 11,
+    BPB_OP_BILINEAR_FWD = 12,
+    BPB_OP_BILINEAR_BWD = 13,
+    BPB_OP_FILL = 14,
+    BPB_OP_CHANNEL_STATS = 15,
+};
+
+// generic op record; slot meaning per kind is documented next to each case
+struct BpbPlanOp {
+    int kind;
+    int i[11];
+    float f[4];
+    double d[2];
+    void* p[12];
+};
+
+extern "C" int bpb_plan_run(const BpbPlanOp* ops, int nops, hipStream_t stream)
+{
+    for (int k = 0; k < nops; ++k) {
+        const BpbPlanOp& o = ops[k];
+        int rc = 0;
+        switch (o.kind) {
+            case BPB_OP_CONV:   // p0 device probs, p1 host probs, i0 nprobs
+                rc = bpb_conv_igemm((const BpbConvProb*)o.p[0], (const BpbConvProb*)o.p[1], o.i[0], stream);
+                break;
+            case BPB_OP_WGRAD:
+                rc = bpb_conv_wgrad((const BpbWgradProb*)o.p[0], (const BpbWgradProb*)o.p[1], o.i[0], stream);
+                break;
+            case BPB_OP_WGRAD_REDUCE:   // p0 ws, p1 dw, i0 nsplit, i1 T, i2 Cin, i3 Cin_real, i4 Cout, i5 accumulate
+                rc = bpb_wgrad_reduce((const float*)o.p[0], (float*)o.p[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], stream);
+                break;
+            case BPB_OP_PACK:   // p0 device probs, i0 nprobs, i1 total blocks
+                rc = bpb_pack_weights((const BpbPackProb*)o.p[0], o.i[0], o.i[1], stream);
+                break;
+            case BPB_OP_BN_FINALIZE:   // p0 partials, i0 nparts, i1 C, d0 count, p1 gamma, p2 beta, f0 eps, f1 momentum,
+                                       // p3 scale, p4 shift, p5 mean, p6 invstd, p7 running_mean, p8 running_var
+                rc = bpb_bn_finalize((const double*)o.p[0], o.i[0], o.i[1], o.d[0], (const float*)o.p[1], (const float*)o.p[2],
+                                     o.f[0], o.f[1], (float*)o.p[3], (float*)o.p[4], (float*)o.p[5], (float*)o.p[6],
+                                     (float*)o.p[7], (float*)o.p[8], stream);
+                break;
+            case BPB_OP_BN_EVAL_AFFINE:   // i0 C, p0 gamma, p1 beta, p2 rm, p3 rv, f0 eps, p4 scale, p5 shift
+                rc = bpb_bn_eval_affine(o.i[0], (const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2],
+                                        (const float*)o.p[3], o.f[0], (float*)o.p[4], (float*)o.p[5], stream);
+                break;
+            case BPB_OP_FUSE_FWD:   // p0 host BpbFuseArgs
+                rc = bpb_fuse_fwd((const BpbFuseArgs*)o.p[0], stream);
+                break;
+            case BPB_OP_TERM_BWD:   // p0 host BpbTermBwdArgs, i0 mode, i1 nblocks
+                rc = bpb_term_bwd((const BpbTermBwdArgs*)o.p[0], o.i[0], o.i[1], stream);
+                break;
+            case BPB_OP_BN_BWD_FINALIZE:   // p0 partials, i0 nparts, i1 C, d0 count, p1 dgamma, p2 dbeta, i2 accumulate, p3 c1, p4 c2
+                rc = bpb_bn_bwd_finalize((const double*)o.p[0], o.i[0], o.i[1], o.d[0], (float*)o.p[1], (float*)o.p[2], o.i[2],
+                                         (float*)o.p[3], (float*)o.p[4], stream);
+                break;
+            case BPB_OP_NCHW_TO_NHWC4:   // p0 x, p1 y, i0 N, i1 C, i2 H, i3 W
+                rc = bpb_nchw_to_nhwc4((const float*)o.p[0], (float*)o.p[1], o.i[0], o.i[1], o.i[2], o.i[3], stream);
+                break;
+            case BPB_OP_MAXPOOL_FWD:   // p0 x, p1 y, p2 idx, i0 N, i1 H, i2 W, i3 C
+                rc = bpb_maxpool3x3s2_fwd((const float*)o.p[0], (float*)o.p[1], (unsigned char*)o.p[2], o.i[0], o.i[1], o.i[2],
+                                          o.i[3], stream);
+                break;
+            case BPB_OP_MAXPOOL_BWD:   // p0 dy, p1 idx, p2 dx, i0 N, i1 H, i2 W, i3 C, i4 accumulate
+                rc = bpb_maxpool3x3s2_bwd((const float*)o.p[0], (const unsigned char*)o.p[1], (float*)o.p[2], o.i[0], o.i[1],
+                                          o.i[2], o.i[3], o.i[4], stream);
+                break;
+            case BPB_OP_BILINEAR_FWD:   // p0 host BpbBilinearArgs
+                rc = bpb_bilinear_concat_fwd((const BpbBilinearArgs*)o.p[0], stream);
+                break;
+            case BPB_OP_BILINEAR_BWD:   // p0 host BpbBilinearArgs, p1 dsrc
+                rc = bpb_bilinear_concat_bwd((const BpbBilinearArgs*)o.p[0], (float*)o.p[1], stream);
+                break;
+            case BPB_OP_FILL:   // p0 x, f0 value, d0 count
+                rc = bpb_fill((float*)o.p[0], o.f[0], (long)o.d[0], stream);
+                break;
+            case BPB_OP_CHANNEL_STATS:   // p0 x, d0 P, i0 C, p1 partials, i1 nblocks
+                rc = bpb_channel_stats((const float*)o.p[0], (long)o.d[0], o.i[0], (double*)o.p[1], o.i[1], stream);
+                break;
+            default:
+                return bpb_set_error(-1, "bpb_plan_run: unknown op kind %d at index %d", o.kind, k);
+        }
+        if (rc != 0) return rc;
+    }
+    return 0;
+}

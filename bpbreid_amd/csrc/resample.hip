@@ -1,0 +1,279 @@
+// Layout / resampling kernels of the backbone (all HBM-bound, NHWC fp32, 16-byte accesses):
+//   * NCHW image batch -> NHWC with C padded 3 -> 4           (boundary: part_based_engine.py:347-351 hands NCHW)
+//   * 3x3 stride-2 max-pool fwd/bwd                            (torchreid/models/resnet.py:217, 346)
+//   * bilinear (align_corners=True) upsample of the four HRNet head branches written straight into
+//     their channel slice of the 1920-channel feature map, fwd/bwd (torchreid/models/hrnet.py:568-573:
+//     F.interpolate x3 + torch.cat become ONE write of the concatenated tensor, no intermediate copies)
+#include "bpb_common.h"
+
+__global__ __launch_bounds__(256) void bpb_nchw_to_nhwc4_kernel(const float* __restrict__ x, float* __restrict__ y, int N,
+                                                                int C, int HW)
+{
+    const long total = (long)N * HW;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+        const long n = i / HW, p = i - n * HW;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < C && c < 4; ++c) v[c] = x[(n * C + c) * HW + p];
+        *(f32x4*)(y + i * 4) = v;
+    }
+}
+
+// NHWC -> NCHW (used for returning pixel-classifier logits and for tests)
+__global__ __launch_bounds__(256) void bpb_nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int N,
+                                                               int C, int HW)
+{
+    const long total = (long)N * C * HW;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+        const long p = i % HW;
+        const long r = i / HW;
+        const int c = (int)(r % C);
+        const long n = r / C;
+        y[i] = x[(n * HW + p) * C + c];
+    }
+}
+
+// ---- max pool 3x3, stride 2, pad 1 ------------------------------------------------------------
+// forward stores the arg-max tap index (0..8, first maximum wins like ATen) as a byte for the backward.
+__global__ __launch_bounds__(256) void bpb_maxpool3x3s2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                   unsigned char* __restrict__ idx, int N, int H, int W,
+                                                                   int C, int Ho, int Wo)
+{
+    const int c4 = C >> 2;
+    const long total = (long)N * Ho * Wo * c4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+        const int cq = (int)(i % c4);
+        long p = i / c4;
+        const int wo = (int)(p % Wo);
+        p /= Wo;
+        const int ho = (int)(p % Ho);
+        const long n = p / Ho;
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int h = ho * 2 - 1 + r, w = wo * 2 - 1 + s;
+                if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+                    const f32x4 v = *(const f32x4*)(x + ((n * H + h) * W + w) * C + cq * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = r * 3 + s; }
+                }
+            }
+        *(f32x4*)(y + i * 4) = best;
+        *(uchar4*)(idx + i * 4) = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2], (unsigned char)bi[3]);
+    }
+}
+
+// gather form (deterministic): dx[h][w] = sum of dy[ho][wo] whose arg-max tap points at (h, w)
+__global__ __launch_bounds__(256) void bpb_maxpool3x3s2_bwd_kernel(const float* __restrict__ dy,
+                                                                   const unsigned char* __restrict__ idx,
+                                                                   float* __restrict__ dx, int N, int H, int W, int C,
+                                                                   int Ho, int Wo, int accumulate)
+{
+    const int c4 = C >> 2;
+    const long total = (long)N * H * W * c4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+        const int cq = (int)(i % c4);
+        long p = i / c4;
+        const int w = (int)(p % W);
+        p /= W;
+        const int h = (int)(p % H);
+        const long n = p / H;
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        // output positions whose window covers (h, w): ho*2-1+r == h  -> ho in {(h+1)/2 .. } with r in 0..2
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int hh = h + 1 - r;
+            if (hh < 0 || (hh & 1)) continue;
+            const int ho = hh >> 1;
+            if (ho >= Ho) continue;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int ww = w + 1 - s;
+                if (ww < 0 || (ww & 1)) continue;
+                const int wo = ww >> 1;
+                if (wo >= Wo) continue;
+                const long o = (((n * Ho + ho) * Wo + wo) * c4 + cq) * 4;
+                const uchar4 k = *(const uchar4*)(idx + o);
+                const f32x4 d = *(const f32x4*)(dy + o);
+                const int tap = r * 3 + s;
+                if (k.x == tap) g[0] += d[0];
+                if (k.y == tap) g[1] += d[1];
+                if (k.z == tap) g[2] += d[2];
+                if (k.w == tap) g[3] += d[3];
+            }
+        }
+        float* o = dx + i * 4;
+        if (accumulate) {
+            const f32x4 old = *(const f32x4*)o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] += old[e];
+        }
+        *(f32x4*)o = g;
+    }
+}
+
+// ---- bilinear (align_corners=True) upsample into a channel slice ----------------------------------
+// ATen semantics (UpSampleBilinear2d, align_corners): scale = (in-1)/(out-1) (0 if out==1), src = scale*dst,
+// i0 = (int)src, i1 = i0 + (i0 < in-1), l1 = src - i0, l0 = 1 - l1;
+// out = l0h*(l0w*v00 + l1w*v01) + l1h*(l0w*v10 + l1w*v11).     scale == 1 degenerates to a copy.
+struct BpbBilinearArgs {
+    const float* src;   // [N][Hs][Ws][Cs]
+    float* dst;         // [N][H][W][Ct], written at channel offset c0
+    int N, Hs, Ws, Cs, H, W, Ct, c0;
+    float sh, sw;       // (Hs-1)/(H-1), (Ws-1)/(W-1) computed in fp32 like ATen
+    int accumulate;     // backward only: dsrc += ...
+};
+
+__global__ __launch_bounds__(256) void bpb_bilinear_concat_fwd_kernel(BpbBilinearArgs A)
+{
+    const int c4 = A.Cs >> 2;
+    const long total = (long)A.N * A.H * A.W * c4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+        const int cq = (int)(i % c4);
+        long p = i / c4;
+        const int w = (int)(p % A.W);
+        p /= A.W;
+        const int h = (int)(p % A.H);
+        const long n = p / A.H;
+        const float fh = A.sh * h, fw = A.sw * w;
+        const int h0 = (int)fh, w0 = (int)fw;
+        const int h1 = h0 + (h0 < A.Hs - 1), w1 = w0 + (w0 < A.Ws - 1);
+        const float lh1 = fh - h0, lw1 = fw - w0, lh0 = 1.f - lh1, lw0 = 1.f - lw1;
+        const float* b = A.src + n * A.Hs * A.Ws * A.Cs + cq * 4;
+        const f32x4 v00 = *(const f32x4*)(b + ((long)h0 * A.Ws + w0) * A.Cs);
+        const f32x4 v01 = *(const f32x4*)(b + ((long)h0 * A.Ws + w1) * A.Cs);
+        const f32x4 v10 = *(const f32x4*)(b + ((long)h1 * A.Ws + w0) * A.Cs);
+        const f32x4 v11 = *(const f32x4*)(b + ((long)h1 * A.Ws + w1) * A.Cs);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = lh0 * (lw0 * v00[e] + lw1 * v01[e]) + lh1 * (lw0 * v10[e] + lw1 * v11[e]);
+        *(f32x4*)(A.dst + ((n * A.H + h) * A.W + w) * A.Ct + A.c0 + cq * 4) = o;
+    }
+}
+
+// backward, gather form (deterministic, no atomics): for each source pixel, visit the destination pixels
+// whose 2x2 footprint contains it and recompute their weights exactly as the forward does.
+// here A.dst is the gradient of the concatenated map (read) and A.src is written (dsrc).
+__global__ __launch_bounds__(256) void bpb_bilinear_concat_bwd_kernel(BpbBilinearArgs A, float* __restrict__ dsrc)
+{
+    const int c4 = A.Cs >> 2;
+    const long total = (long)A.N * A.Hs * A.Ws * c4;
+    const float inv_sh = A.sh > 0.f ? 1.f / A.sh : 0.f, inv_sw = A.sw > 0.f ? 1.f / A.sw : 0.f;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+        const int cq = (int)(i % c4);
+        long p = i / c4;
+        const int ws = (int)(p % A.Ws);
+        p /= A.Ws;
+        const int hs = (int)(p % A.Hs);
+        const long n = p / A.Hs;
+        // conservative destination ranges: rows h with (int)(sh*h) in {hs-1, hs}
+        int hlo = 0, hhi = A.H - 1, wlo = 0, whi = A.W - 1;
+        if (A.sh > 0.f) {
+            hlo = max(0, (int)floorf((hs - 1) * inv_sh) - 1);
+            hhi = min(A.H - 1, (int)ceilf((hs + 1) * inv_sh) + 1);
+        }
+        if (A.sw > 0.f) {
+            wlo = max(0, (int)floorf((ws - 1) * inv_sw) - 1);
+            whi = min(A.W - 1, (int)ceilf((ws + 1) * inv_sw) + 1);
+        }
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        for (int h = hlo; h <= hhi; ++h) {
+            const float fh = A.sh * h;
+            const int h0 = (int)fh, h1 = h0 + (h0 < A.Hs - 1);
+            const float lh1 = fh - h0, lh0 = 1.f - lh1;
+            float wh = 0.f;
+            if (h0 == hs) wh += lh0;
+            if (h1 == hs) wh += lh1;     // h0 == h1 at the border: both weights land on the same pixel
+            if (h0 != hs && h1 != hs) continue;
+            for (int w = wlo; w <= whi; ++w) {
+                const float fw = A.sw * w;
+                const int w0 = (int)fw, w1 = w0 + (w0 < A.Ws - 1);
+                if (w0 != ws && w1 != ws) continue;
+                const float lw1 = fw - w0, lw0 = 1.f - lw1;
+                float ww = 0.f;
+                if (w0 == ws) ww += lw0;
+                if (w1 == ws) ww += lw1;
+                const f32x4 d = *(const f32x4*)(A.dst + ((n * A.H + h) * A.W + w) * A.Ct + A.c0 + cq * 4);
+                const float k = wh * ww;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] += k * d[e];
+            }
+        }
+        float* o = dsrc + i * 4;
+        if (A.accumulate) {
+            const f32x4 old = *(const f32x4*)o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] += old[e];
+        }
+        *(f32x4*)o = g;
+    }
+}
+
+static int ew_grid(long total_vec)
+{
+    long g = (total_vec + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" {
+
+int bpb_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, hipStream_t stream)
+{
+    BPB_REQUIRE(C >= 1 && C <= 4, "bpb_nchw_to_nhwc4: C=%d", C);
+    hipLaunchKernelGGL(bpb_nchw_to_nhwc4_kernel, dim3(ew_grid((long)N * H * W)), dim3(256), 0, stream, x, y, N, C, H * W);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, hipStream_t stream)
+{
+    hipLaunchKernelGGL(bpb_nhwc_to_nchw_kernel, dim3(ew_grid((long)N * C * H * W)), dim3(256), 0, stream, x, y, N, C, H * W);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_maxpool3x3s2_fwd(const float* x, float* y, unsigned char* idx, int N, int H, int W, int C, hipStream_t stream)
+{
+    BPB_REQUIRE(C % 4 == 0, "bpb_maxpool: C must be a multiple of 4");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(bpb_maxpool3x3s2_fwd_kernel, dim3(ew_grid((long)N * Ho * Wo * (C / 4))), dim3(256), 0, stream, x, y,
+                       idx, N, H, W, C, Ho, Wo);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_maxpool3x3s2_bwd(const float* dy, const unsigned char* idx, float* dx, int N, int H, int W, int C, int accumulate,
+                         hipStream_t stream)
+{
+    BPB_REQUIRE(C % 4 == 0, "bpb_maxpool: C must be a multiple of 4");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(bpb_maxpool3x3s2_bwd_kernel, dim3(ew_grid((long)N * H * W * (C / 4))), dim3(256), 0, stream, dy, idx,
+                       dx, N, H, W, C, Ho, Wo, accumulate);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_bilinear_concat_fwd(const BpbBilinearArgs* a, hipStream_t stream)
+{
+    BPB_REQUIRE(a->Cs % 4 == 0 && a->Ct % 4 == 0 && a->c0 % 4 == 0, "bpb_bilinear_concat: channels must be multiples of 4");
+    hipLaunchKernelGGL(bpb_bilinear_concat_fwd_kernel, dim3(ew_grid((long)a->N * a->H * a->W * (a->Cs / 4))), dim3(256), 0,
+                       stream, *a);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_bilinear_concat_bwd(const BpbBilinearArgs* a, float* dsrc, hipStream_t stream)
+{
+    BPB_REQUIRE(a->Cs % 4 == 0 && a->Ct % 4 == 0 && a->c0 % 4 == 0, "bpb_bilinear_concat: channels must be multiples of 4");
+    hipLaunchKernelGGL(bpb_bilinear_concat_bwd_kernel, dim3(ew_grid((long)a->N * a->Hs * a->Ws * (a->Cs / 4))), dim3(256),
+                       0, stream, *a, dsrc);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+}   // extern "C"

@@ -1,0 +1,162 @@
+"""ctypes binding of libbpbreid_hip.so (the C-ABI of include/bpbreid_hip.h).
+
+The library is the product: if it cannot be loaded this module raises -- there is no CPU or
+PyTorch fallback anywhere in bpbreid_amd.  PyTorch only provides device memory (tensors whose
+``data_ptr()`` is handed to the kernels), the current HIP stream and torch.distributed.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libbpbreid_hip.so')
+
+c_fp = C.c_void_p
+
+
+class ConvProb(C.Structure):
+    _fields_ = [('x', c_fp), ('w', c_fp), ('y', c_fp), ('bias', c_fp), ('stats', c_fp)] + [
+        (n, C.c_int) for n in (
+            'N', 'Hi', 'Wi', 'Cin', 'Ho', 'Wo', 'Cout', 'A', 'B', 'osh', 'osw', 'ooh', 'oow', 'sa', 'ih0', 'iw0',
+            'Rt', 'St', 'dh0', 'dhs', 'dw0', 'dws', 'w0', 'wrs', 'wss', 'lTI', 'lTH', 'lTW', 'HH', 'HW', 'CK', 'LD',
+            'tiles_a', 'tiles_b', 'n_mtiles', 'n_ntiles', 'blk_begin', 'accumulate')] + [
+        ('magic_hw', C.c_uint), ('magic_hh', C.c_uint)]
+
+
+class WgradProb(C.Structure):
+    _fields_ = [('x', c_fp), ('dy', c_fp), ('ws', c_fp)] + [
+        (n, C.c_int) for n in (
+            'N', 'Hi', 'Wi', 'Cin', 'A', 'B', 'Cout', 'sa', 'ih0', 'iw0', 'T', 'S', 'lTI', 'lTH', 'lTW', 'HH', 'HW',
+            'LD', 'tiles_a', 'tiles_b', 'n_mtiles', 'n_citiles', 'n_cotiles', 'n_tapgroups', 'nsplit', 'blk_begin')] + [
+        ('magic_hw', C.c_uint), ('magic_hh', C.c_uint)]
+
+
+class PackProb(C.Structure):
+    _fields_ = [('w', c_fp), ('wf', c_fp), ('wd', c_fp), ('Cout', C.c_int), ('Cin', C.c_int), ('Cin_pad', C.c_int),
+                ('T', C.c_int), ('blk_begin', C.c_int)]
+
+
+class FuseArgs(C.Structure):
+    _fields_ = [('out', c_fp), ('src', c_fp * 4), ('scale', c_fp * 4), ('shift', c_fp * 4), ('up', C.c_int * 4),
+                ('nterms', C.c_int), ('N', C.c_int), ('H', C.c_int), ('W', C.c_int), ('C', C.c_int), ('relu', C.c_int),
+                ('magic_w', C.c_uint), ('magic_h', C.c_uint)]
+
+
+class TermBwdArgs(C.Structure):
+    _fields_ = [('dout', c_fp), ('out', c_fp), ('src', c_fp), ('mean', c_fp), ('invstd', c_fp), ('scale', c_fp),
+                ('c1', c_fp), ('c2', c_fp), ('dsrc', c_fp), ('partials', c_fp),
+                ('N', C.c_int), ('Hs', C.c_int), ('Ws', C.c_int), ('C', C.c_int), ('up', C.c_int),
+                ('relu', C.c_int), ('accumulate', C.c_int), ('magic_w', C.c_uint), ('magic_h', C.c_uint)]
+
+
+class BilinearArgs(C.Structure):
+    _fields_ = [('src', c_fp), ('dst', c_fp)] + [(n, C.c_int) for n in ('N', 'Hs', 'Ws', 'Cs', 'H', 'W', 'Ct', 'c0')] + [
+        ('sh', C.c_float), ('sw', C.c_float), ('accumulate', C.c_int)]
+
+
+class PlanOp(C.Structure):
+    _fields_ = [('kind', C.c_int), ('i', C.c_int * 11), ('f', C.c_float * 4), ('d', C.c_double * 2), ('p', c_fp * 12)]
+
+
+(OP_CONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL_AFFINE, OP_FUSE_FWD, OP_TERM_BWD,
+ OP_BN_BWD_FINALIZE, OP_NCHW_TO_NHWC4, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_BILINEAR_FWD, OP_BILINEAR_BWD, OP_FILL,
+ OP_CHANNEL_STATS) = range(16)
+
+
+def magic(d):
+    """ceil(2^32 / d) for the kernels' multiply-high division (d == 1 is special-cased in the kernels)."""
+    return 0 if d <= 1 else (-(-(1 << 32) // d)) & 0xFFFFFFFF
+
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it is missing -- no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                'bpbreid_amd: %s not found. Build it with `python -m bpbreid_amd.build` '
+                '(hipcc --offload-arch=gfx950); there is no CPU/PyTorch fallback.' % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.bpb_last_error.restype = C.c_char_p
+        kinds = {'p': C.c_void_p, 'i': C.c_int, 'l': C.c_long, 'f': C.c_float, 'd': C.c_double}
+        for name, sig in PROTOS.items():
+            fn = getattr(L, name)          # AttributeError here = header/library mismatch: fail loudly
+            fn.argtypes = [kinds[ch] for ch in sig]
+            fn.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+_inited = False
+
+
+def init_device():
+    """One-time per process: raise the dynamic-LDS limit of the big-tile kernels (needs a GPU)."""
+    global _inited
+    if not _inited:
+        check(lib().bpb_conv_init())
+        check(lib().bpb_head_init())
+        _inited = True
+
+
+def check(rc):
+    if rc != 0:
+        raise NativeError('bpbreid_hip error %d: %s' % (rc, lib().bpb_last_error().decode()))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  The caller keeps the tensor alive."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name, *args):
+    """Invoke an extern "C" entry point with automatic error checking."""
+    check(getattr(lib(), name)(*args))
+
+
+# argument kinds of every entry point: p pointer, i int, l long, f float, d double (stream = last 'p')
+PROTOS = {
+    'bpb_conv_init': '', 'bpb_head_init': '',
+    'bpb_conv_igemm': 'ppip', 'bpb_conv_wgrad': 'ppip', 'bpb_wgrad_reduce': 'ppiiiiiip', 'bpb_pack_weights': 'piip',
+    'bpb_bn_finalize': 'piidppffppppppp', 'bpb_bn_eval_affine': 'ippppfppp', 'bpb_channel_stats': 'plipip',
+    'bpb_fuse_fwd': 'pp', 'bpb_term_bwd': 'piip', 'bpb_bn_bwd_finalize': 'piidppippp',
+    'bpb_nchw_to_nhwc4': 'ppiiiip', 'bpb_nhwc_to_nchw': 'ppiiiip',
+    'bpb_maxpool3x3s2_fwd': 'pppiiiip', 'bpb_maxpool3x3s2_bwd': 'pppiiiiip',
+    'bpb_bilinear_concat_fwd': 'pp', 'bpb_bilinear_concat_bwd': 'ppp',
+    'bpb_pixel_dots': 'pplppiiiip', 'bpb_masked_pool': 'pppiiiipp', 'bpb_fold_bn': 'ppppppiip',
+    'bpb_softmax_masks': 'ppppppiiip', 'bpb_visibility': 'ppppiiiip', 'bpb_pool_finalize': 'ppppiiiiip',
+    'bpb_rowdot': 'pppiip', 'bpb_head_bwd_dlogits': 'pppppppiiip',
+    'bpb_head_bwd_params': 'pipiiiipppppppppppip', 'bpb_head_bwd_dx': 'ppppppppppppiiiiip',
+    'bpb_gemm': 'pllpllplpiiiippp', 'bpb_colsum': 'ppiiip',
+    'bpb_bn1d_fwd': 'plpliippppppffiip', 'bpb_bn1d_bwd': 'plplplpliipppppiip',
+    'bpb_ce_label_smooth': 'plpipiiifppplpp', 'bpb_pixel_ce': 'ppiiiiiifppipp',
+    'bpb_part_triplet': 'pllppipiiiiffpppppp', 'bpb_part_triplet_bwd': 'pllppfiiipllip',
+    'bpb_scale': 'ppfplip', 'bpb_adam_step': 'ppppppifffffifp', 'bpb_fill': 'pflp', 'bpb_plan_run': 'pip',
+    'bpb_part_distance': 'ppppiiiiiiipppppip', 'bpb_part_distance_fill': 'plpp',
+    'bpb_eval_rank': 'pppppiiiipppp',
+}
+
+EXPORTS = [
+    'bpb_last_error', 'bpb_conv_init', 'bpb_head_init', 'bpb_conv_igemm', 'bpb_conv_wgrad', 'bpb_wgrad_reduce',
+    'bpb_pack_weights', 'bpb_bn_finalize', 'bpb_bn_eval_affine', 'bpb_channel_stats', 'bpb_fuse_fwd', 'bpb_term_bwd',
+    'bpb_bn_bwd_finalize', 'bpb_nchw_to_nhwc4', 'bpb_nhwc_to_nchw', 'bpb_maxpool3x3s2_fwd', 'bpb_maxpool3x3s2_bwd',
+    'bpb_bilinear_concat_fwd', 'bpb_bilinear_concat_bwd', 'bpb_pixel_dots', 'bpb_masked_pool', 'bpb_fold_bn',
+    'bpb_softmax_masks', 'bpb_visibility', 'bpb_pool_finalize', 'bpb_rowdot', 'bpb_head_bwd_dlogits',
+    'bpb_head_bwd_params', 'bpb_head_bwd_dx', 'bpb_gemm', 'bpb_colsum', 'bpb_bn1d_fwd', 'bpb_bn1d_bwd',
+    'bpb_ce_label_smooth', 'bpb_pixel_ce', 'bpb_part_triplet', 'bpb_part_triplet_bwd', 'bpb_scale', 'bpb_adam_step',
+    'bpb_fill', 'bpb_plan_run', 'bpb_part_distance', 'bpb_part_distance_fill', 'bpb_eval_rank',
+]
