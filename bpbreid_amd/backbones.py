@@ -1,0 +1,223 @@
+"""HRNet (W32 / W48 / any width) and ResNet-50 trunks for the MI355X plan executor.
+
+Each class is (a) a *parameter holder* whose state-dict keys equal the reference's
+(torchreid/models/hrnet.py:314-576, torchreid/models/resnet.py:157-358) so the
+authors' checkpoints load unchanged, and (b) an ``emit(net, x)`` method that records the network into a
+``graph.Net`` launch plan instead of executing nn.Module calls.  The nn.Conv2d / nn.BatchNorm2d children
+are never called: they only own the tensors (which live in one flat arena, see model.py).
+"""
+import torch.nn as nn
+
+
+def _bn_tuple(bn):
+    return (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+
+
+def _emit_cb(net, x, conv, bn):
+    """conv + BatchNorm batch statistics; the affine itself is applied by the consuming fuse op."""
+    assert conv.bias is None
+    return net.conv(x, conv.weight, conv.stride[0], conv.padding[0], bn=_bn_tuple(bn))
+
+
+def _cb(cin, cout, k, stride=1, relu=False, bias=False):
+    mods = [nn.Conv2d(cin, cout, k, stride, k // 2, bias=bias), nn.BatchNorm2d(cout)]
+    if relu:
+        mods.append(nn.ReLU())
+    return nn.Sequential(*mods)
+
+
+class Residual(nn.Module):
+    """BasicBlock (hrnet.py:67-96) or Bottleneck (hrnet.py:99-137, resnet.py:105-154)."""
+
+    def __init__(self, cin, planes, bottleneck, stride=1):
+        super().__init__()
+        self.bottleneck = bottleneck
+        cout = planes * (4 if bottleneck else 1)
+        if bottleneck:
+            self.conv1 = nn.Conv2d(cin, planes, 1, bias=False)
+            self.bn1 = nn.BatchNorm2d(planes)
+            self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+            self.bn2 = nn.BatchNorm2d(planes)
+            self.conv3 = nn.Conv2d(planes, cout, 1, bias=False)
+            self.bn3 = nn.BatchNorm2d(cout)
+        else:
+            self.conv1 = nn.Conv2d(cin, planes, 3, stride, 1, bias=False)
+            self.bn1 = nn.BatchNorm2d(planes)
+            self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+            self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+        self.cout = cout
+
+    def emit(self, net, x):
+        c = _emit_cb(net, x, self.conv1, self.bn1)
+        a = net.fuse([(c, 0)], relu=True)
+        c = _emit_cb(net, a, self.conv2, self.bn2)
+        if self.bottleneck:
+            a = net.fuse([(c, 0)], relu=True)
+            c = _emit_cb(net, a, self.conv3, self.bn3)
+        skip = x if self.downsample is None else _emit_cb(net, x, self.downsample[0], self.downsample[1])
+        return net.fuse([(c, 0), (skip, 0)], relu=True)      # bn(conv) + residual, then ReLU: one pass
+
+
+def _chain(cin, planes, n, bottleneck, stride=1):
+    units = [Residual(cin, planes, bottleneck, stride)]
+    for _ in range(n - 1):
+        units.append(Residual(units[0].cout, planes, bottleneck))
+    return nn.Sequential(*units)
+
+
+def _emit_chain(net, chain, x):
+    for unit in chain:
+        x = unit.emit(net, x)
+    return x
+
+
+class MultiResModule(nn.Module):
+    """HighResolutionModule (hrnet.py:140-279)."""
+
+    def __init__(self, widths, blocks_per_branch=4):
+        super().__init__()
+        nb = len(widths)
+        self.branches = nn.ModuleList([_chain(w, w, blocks_per_branch, False) for w in widths])
+        rows = []
+        for i in range(nb):
+            row = []
+            for j in range(nb):
+                if j > i:
+                    row.append(nn.Sequential(nn.Conv2d(widths[j], widths[i], 1, bias=False), nn.BatchNorm2d(widths[i]),
+                                             nn.Upsample(scale_factor=2 ** (j - i), mode='nearest')))
+                elif j == i:
+                    row.append(None)
+                else:
+                    steps = []
+                    for k in range(i - j):
+                        last = (k == i - j - 1)
+                        steps.append(_cb(widths[j], widths[i] if last else widths[j], 3, 2, relu=not last))
+                    row.append(nn.Sequential(*steps))
+            rows.append(nn.ModuleList(row))
+        self.fuse_layers = nn.ModuleList(rows)
+
+    def emit(self, net, xs):
+        xs = [_emit_chain(net, b, x) for b, x in zip(self.branches, xs)]
+        # Down-paths of different targets share nothing, up-paths are 1x1 conv + BN whose nearest upsample is
+        # folded into the fuse read (no upsampled tensor is ever written).
+        outs = []
+        for i, row in enumerate(self.fuse_layers):
+            terms = []
+            for j, x in enumerate(xs):
+                if j == i:
+                    terms.append((x, 0))
+                elif j > i:
+                    terms.append((_emit_cb(net, x, row[j][0], row[j][1]), j - i))
+                else:
+                    t = x
+                    steps = list(row[j])
+                    for k, st in enumerate(steps):
+                        c = _emit_cb(net, t, st[0], st[1])
+                        if k < len(steps) - 1:
+                            t = net.fuse([(c, 0)], relu=True)
+                        else:
+                            terms.append((c, 0))
+            outs.append(net.fuse(terms, relu=True))
+        return outs
+
+
+class HRNet(nn.Module):
+    def __init__(self, widths=(32, 64, 128, 256), modules=(1, 4, 3), enable_dim_reduction=False,
+                 dim_reduction_channels=256):
+        super().__init__()
+        widths = list(widths)
+        self.conv1 = nn.Conv2d(3, 64, 3, 2, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.conv2 = nn.Conv2d(64, 64, 3, 2, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(64)
+        self.layer1 = _chain(64, 64, 4, True)
+        prev = [256]
+        for s, nmod in enumerate(modules):
+            cur = widths[:s + 2]
+            trans = []
+            for i, w in enumerate(cur):
+                if i < len(prev):
+                    trans.append(_cb(prev[i], w, 3, 1, relu=True) if prev[i] != w else None)
+                else:
+                    steps = []
+                    for j in range(i + 1 - len(prev)):
+                        steps.append(_cb(prev[-1], w if j == i - len(prev) else prev[-1], 3, 2, relu=True))
+                    trans.append(nn.Sequential(*steps))
+            setattr(self, 'transition%d' % (s + 1), nn.ModuleList(trans))
+            setattr(self, 'stage%d' % (s + 2), nn.Sequential(*[MultiResModule(cur) for _ in range(nmod)]))
+            prev = cur
+        head = [32, 64, 128, 256]
+        self.incre_modules = nn.ModuleList([_chain(w, h, 1, True) for w, h in zip(widths, head)])
+        self.layers_out_channels = sum(h * 4 for h in head)
+        self.cls_head = _cb(self.layers_out_channels, dim_reduction_channels, 1, relu=True, bias=True)
+        if enable_dim_reduction:
+            raise NotImplementedError("dim_reduce='before_pooling' (cls_head) is not on the accelerated path")
+        self.feature_dim = self.layers_out_channels
+        self.nstages = len(modules)
+        self.reduction = 4
+
+    def emit(self, net, x):
+        c = _emit_cb(net, x, self.conv1, self.bn1)
+        x = net.fuse([(c, 0)], relu=True)
+        c = _emit_cb(net, x, self.conv2, self.bn2)
+        x = net.fuse([(c, 0)], relu=True)
+        ys = [_emit_chain(net, self.layer1, x)]
+        for s in range(self.nstages):
+            trans = getattr(self, 'transition%d' % (s + 1))
+            xs = []
+            for i, t in enumerate(trans):
+                if t is None:
+                    xs.append(ys[i])
+                    continue
+                src = ys[0] if s == 0 else ys[-1]           # hrnet.py:541-563
+                if isinstance(t[0], nn.Conv2d):              # same-resolution transition: conv, bn, relu
+                    src = net.fuse([(_emit_cb(net, src, t[0], t[1]), 0)], relu=True)
+                else:                                        # chain of strided conv-bn-relu
+                    for st in t:
+                        src = net.fuse([(_emit_cb(net, src, st[0], st[1]), 0)], relu=True)
+                xs.append(src)
+            for mod in getattr(self, 'stage%d' % (s + 2)):
+                xs = mod.emit(net, xs)
+            ys = xs
+        ys = [_emit_chain(net, m, y) for m, y in zip(self.incre_modules, ys)]
+        return net.concat_bilinear(ys)
+
+
+class ResNet50(nn.Module):
+    def __init__(self, num_classes, last_stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.layer1 = _chain(64, 64, 3, True)
+        self.layer2 = _chain(256, 128, 4, True, 2)
+        self.layer3 = _chain(512, 256, 6, True, 2)
+        self.layer4 = _chain(1024, 512, 3, True, last_stride)
+        self.classifier = nn.Linear(2048, num_classes)   # present in the reference state dict, unused on this path
+        self.feature_dim = 2048
+
+    def emit(self, net, x):
+        c = _emit_cb(net, x, self.conv1, self.bn1)
+        x = net.fuse([(c, 0)], relu=True)
+        x = net.maxpool(x)
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            x = _emit_chain(net, layer, x)
+        return x
+
+
+def build_backbone(name, num_classes, last_stride=1, enable_dim_reduction=False, dim_reduction_channels=256, **_):
+    if name == 'hrnet32':
+        return HRNet((32, 64, 128, 256), enable_dim_reduction=enable_dim_reduction,
+                     dim_reduction_channels=dim_reduction_channels)
+    if name == 'hrnet48':
+        return HRNet((48, 96, 192, 384), enable_dim_reduction=enable_dim_reduction,
+                     dim_reduction_channels=dim_reduction_channels)
+    if name.startswith('hrnet_w'):
+        w = int(name[len('hrnet_w'):])
+        return HRNet((w, 2 * w, 4 * w, 8 * w), enable_dim_reduction=enable_dim_reduction,
+                     dim_reduction_channels=dim_reduction_channels)
+    if name == 'resnet50':
+        return ResNet50(num_classes, last_stride)
+    raise KeyError('Unknown backbone: %s' % name)

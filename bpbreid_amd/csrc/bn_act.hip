@@ -11,7 +11,6 @@
 // partials emitted by the conv epilogue (conv_igemm.hip) -> bpb_bn_finalize -> (scale, shift).
 #include "bpb_common.h"
 
-#define BPB_MAX_TERMS 4
 
 // ---- (1) batch statistics -> affine, running stats (nn.BatchNorm2d training semantics) ----------
 // partials: [nparts][2][C] doubles (sum, sumsq).  count = elements per channel.
@@ -131,17 +130,6 @@ __global__ __launch_bounds__(256) void bpb_channel_stats_kernel(const float* __r
 }
 
 // ---- (2) fused forward: out = act(sum_t affine_t(up_t(src_t))) -----------------------------------
-struct BpbFuseArgs {
-    float* out;                         // [N][H][W][C]
-    const float* src[BPB_MAX_TERMS];    // term t: [N][H>>up][W>>up][C]
-    const float* scale[BPB_MAX_TERMS];  // nullptr -> identity term
-    const float* shift[BPB_MAX_TERMS];
-    int up[BPB_MAX_TERMS];              // log2 nearest-upsample factor
-    int nterms;
-    int N, H, W, C;
-    int relu;
-    unsigned magic_w, magic_h;          // ceil(2^32 / W), ceil(2^32 / H)
-};
 
 __device__ __forceinline__ unsigned bpb_fdiv2(unsigned x, unsigned d, unsigned magic)
 {
@@ -194,21 +182,6 @@ __global__ __launch_bounds__(256) void bpb_fuse_fwd_kernel(BpbFuseArgs A)
 
 // ---- (3) backward of one term ------------------------------------------------------------------
 // G[q][c] = sum over the 2^up x 2^up window of dout * (out > 0 if relu).
-struct BpbTermBwdArgs {
-    const float* dout;      // [N][H][W][C] gradient wrt `out`
-    const float* out;       // forward output (ReLU mask), may be nullptr when relu == 0
-    const float* src;       // forward input of the term (conv raw output) [N][Hs][Ws][C]; BN terms only
-    const float* mean;      // BN terms: saved batch mean / invstd / scale(gamma*invstd)
-    const float* invstd;
-    const float* scale;
-    const float* c1;        // BN apply: per-channel sum(G)/M and sum(G*xhat)/M
-    const float* c2;
-    float* dsrc;            // gradient wrt src
-    double* partials;       // BN reduce: [nblocks][2][C]
-    int N, Hs, Ws, C, up;   // src spatial dims; out dims are Hs<<up, Ws<<up
-    int relu, accumulate;
-    unsigned magic_w, magic_h;   // for Ws, Hs
-};
 
 __device__ __forceinline__ f32x4 bpb_window_grad(const BpbTermBwdArgs& A, long q, int cq)
 {

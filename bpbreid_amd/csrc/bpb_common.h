@@ -10,12 +10,12 @@
 //    MFMA A/B fragments are 16-byte vector loads.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "../../include/bpbreid_hip.h"
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
 
 
-extern "C" const char* bpb_last_error(void);
 int bpb_set_error(int code, const char* fmt, ...);
 
 #define BPB_REQUIRE(cond, ...)                         \
@@ -52,27 +52,3 @@ static inline int bpb_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // dgrad with one kernel.  W is pre-packed as [tap][Cin/4][Cout][4] (k-quad innermost) so the
 // MFMA B fragment of four consecutive k-steps is one 16-byte load.
 // ---------------------------------------------------------------------------------------
-struct BpbConvProb {
-    const float* x;
-    const float* w;
-    float* y;
-    const float* bias;      // optional [Cout]
-    double* stats;          // optional [n_mtiles][2][Cout] per-tile (sum, sumsq) partials for BatchNorm
-    int N, Hi, Wi, Cin;     // input tensor dims (Cin multiple of 8, or == 4)
-    int Ho, Wo, Cout;       // output tensor dims
-    int A, B;               // logical output grid handled by this problem
-    int osh, osw, ooh, oow; // logical -> output coordinate map
-    int sa;                 // input step per logical step
-    int ih0, iw0;           // input origin
-    // regular tap grid: tap (i, j), i < Rt, j < St reads input offset (dh0 + dhs*i, dw0 + dws*j) >= 0 relative to
-    // (ih0, iw0) and uses packed-weight slice w0 + wrs*i + wss*j.  Covers full filters (forward, stride-1 dgrad)
-    // and the per-parity tap subsets of strided dgrad without any table lookup in the inner loop.
-    int Rt, St, dh0, dhs, dw0, dws, w0, wrs, wss;
-    int lTI, lTH, lTW;      // log2 of the M-tile factorisation TI x TH x TW (= 256 pixels)
-    int HH, HW;             // halo tile dims
-    int CK, LD;             // channel chunk staged per pass and LDS row pitch (floats)
-    int tiles_a, tiles_b, n_mtiles, n_ntiles;
-    int blk_begin;          // first blockIdx of this problem inside a grouped launch
-    int accumulate;         // y += result
-    unsigned magic_hw, magic_hh;   // ceil(2^32/d) for d = HW, HH (staging index split without idiv)
-};

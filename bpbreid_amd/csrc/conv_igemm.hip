@@ -223,21 +223,6 @@ __global__ __launch_bounds__(256) void bpb_conv_igemm_kernel(const BpbConvProb* 
 // the pixels, accumulate in registers over the whole range, reduce through LDS and write ONE
 // partial slab; bpb_wgrad_reduce_kernel sums the slabs in a fixed order (deterministic) into OIHW.
 // ---------------------------------------------------------------------------------------
-struct BpbWgradProb {
-    const float* x;        // NHWC input of the conv
-    const float* dy;       // NHWC grad of the conv output [N][A][B][Cout]
-    float* ws;             // partial slabs [nsplit][T][Cin][Cout]
-    int N, Hi, Wi, Cin;
-    int A, B, Cout;
-    int sa, ih0, iw0;
-    int T, S;              // total taps (R*S) and filter width; tap t reads input offset (t / S, t % S)
-    int lTI, lTH, lTW;     // 128-pixel tile factorisation
-    int HH, HW, LD;
-    int tiles_a, tiles_b, n_mtiles;
-    int n_citiles, n_cotiles, n_tapgroups, nsplit;
-    int blk_begin;
-    unsigned magic_hw, magic_hh;
-};
 
 template <int TG, int NTW>   // TG = taps per group (9 for spatial filters, 1 for 1x1), NTW = 32-wide co sub-tiles
 __global__ __launch_bounds__(256) void bpb_conv_wgrad_kernel(const BpbWgradProb* __restrict__ probs, int nprobs)
@@ -391,13 +376,6 @@ __global__ void bpb_wgrad_reduce_kernel(const float* __restrict__ ws, float* __r
 //   fwd   wf[t][ci/4][co][4]  = W[co][ci][t]            (ci zero-padded to Cin_pad)
 //   dgrad wd[t][co/4][ci][4]  = W[co][ci][t]            (only when wd != nullptr)
 // ---------------------------------------------------------------------------------------
-struct BpbPackProb {
-    const float* w;   // OIHW
-    float* wf;
-    float* wd;
-    int Cout, Cin, Cin_pad, T;
-    int blk_begin;
-};
 
 __global__ void bpb_pack_weights_kernel(const BpbPackProb* __restrict__ probs, int nprobs)
 {

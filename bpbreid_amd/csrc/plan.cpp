@@ -6,61 +6,6 @@
 // The same array can be recorded into a hipGraph by capturing the stream around bpb_plan_run.
 #include "bpb_common.h"
 
-struct BpbConvProb;
-struct BpbWgradProb;
-struct BpbPackProb;
-struct BpbFuseArgs;
-struct BpbTermBwdArgs;
-struct BpbBilinearArgs;
-
-extern "C" {
-int bpb_conv_igemm(const BpbConvProb*, const BpbConvProb*, int, hipStream_t);
-int bpb_conv_wgrad(const BpbWgradProb*, const BpbWgradProb*, int, hipStream_t);
-int bpb_wgrad_reduce(const float*, float*, int, int, int, int, int, int, hipStream_t);
-int bpb_pack_weights(const BpbPackProb*, int, int, hipStream_t);
-int bpb_bn_finalize(const double*, int, int, double, const float*, const float*, float, float, float*, float*, float*,
-                    float*, float*, float*, hipStream_t);
-int bpb_bn_eval_affine(int, const float*, const float*, const float*, const float*, float, float*, float*, hipStream_t);
-int bpb_channel_stats(const float*, long, int, double*, int, hipStream_t);
-int bpb_fuse_fwd(const BpbFuseArgs*, hipStream_t);
-int bpb_term_bwd(const BpbTermBwdArgs*, int, int, hipStream_t);
-int bpb_bn_bwd_finalize(const double*, int, int, double, float*, float*, int, float*, float*, hipStream_t);
-int bpb_nchw_to_nhwc4(const float*, float*, int, int, int, int, hipStream_t);
-int bpb_maxpool3x3s2_fwd(const float*, float*, unsigned char*, int, int, int, int, hipStream_t);
-int bpb_maxpool3x3s2_bwd(const float*, const unsigned char*, float*, int, int, int, int, int, hipStream_t);
-int bpb_bilinear_concat_fwd(const BpbBilinearArgs*, hipStream_t);
-int bpb_bilinear_concat_bwd(const BpbBilinearArgs*, float*, hipStream_t);
-int bpb_fill(float*, float, long, hipStream_t);
-}
-
-enum BpbOpKind {
-    BPB_OP_CONV = 0,
-    BPB_OP_WGRAD = 1,
-    BPB_OP_WGRAD_REDUCE = 2,
-    BPB_OP_PACK = 3,
-    BPB_OP_BN_FINALIZE = 4,
-    BPB_OP_BN_EVAL_AFFINE = 5,
-    BPB_OP_FUSE_FWD = 6,
-    BPB_OP_TERM_BWD = 7,
-    BPB_OP_BN_BWD_FINALIZE = 8,
-    BPB_OP_NCHW_TO_NHWC4 = 9,
-    BPB_OP_MAXPOOL_FWD = 10,
-    BPB_OP_MAXPOOL_BWD = 11,
-    BPB_OP_BILINEAR_FWD = 12,
-    BPB_OP_BILINEAR_BWD = 13,
-    BPB_OP_FILL = 14,
-    BPB_OP_CHANNEL_STATS = 15,
-};
-
-// generic op record; slot meaning per kind is documented next to each case
-struct BpbPlanOp {
-    int kind;
-    int i[11];
-    float f[4];
-    double d[2];
-    void* p[12];
-};
-
 extern "C" int bpb_plan_run(const BpbPlanOp* ops, int nops, hipStream_t stream)
 {
     for (int k = 0; k < nops; ++k) {

@@ -119,13 +119,6 @@ __global__ __launch_bounds__(256) void bpb_maxpool3x3s2_bwd_kernel(const float* 
 // ATen semantics (UpSampleBilinear2d, align_corners): scale = (in-1)/(out-1) (0 if out==1), src = scale*dst,
 // i0 = (int)src, i1 = i0 + (i0 < in-1), l1 = src - i0, l0 = 1 - l1;
 // out = l0h*(l0w*v00 + l1w*v01) + l1h*(l0w*v10 + l1w*v11).     scale == 1 degenerates to a copy.
-struct BpbBilinearArgs {
-    const float* src;   // [N][Hs][Ws][Cs]
-    float* dst;         // [N][H][W][Ct], written at channel offset c0
-    int N, Hs, Ws, Cs, H, W, Ct, c0;
-    float sh, sw;       // (Hs-1)/(H-1), (Ws-1)/(W-1) computed in fp32 like ATen
-    int accumulate;     // backward only: dsrc += ...
-};
 
 __global__ __launch_bounds__(256) void bpb_bilinear_concat_fwd_kernel(BpbBilinearArgs A)
 {

@@ -1,0 +1,141 @@
+"""Train/eval engine for the part-based path: the MI355X counterpart of
+torchreid/engine/image/part_based_engine.py (ImagePartBasedEngine) reduced to the hot path.
+
+Same method names and data contract (batch dict keys 'image', 'mask', 'pid', 'camid'):
+    forward_backward(data) -> (loss, loss_summary)                          part_based_engine.py:77-105
+    combine_losses(...)                                                      part_based_engine.py:107-130
+    extract_test_embeddings(model_output)                                    part_based_engine.py:365-387
+    evaluate(...)  (feature normalisation + part-based distance + CMC/mAP)   part_based_engine.py:168-240
+What is deliberately NOT copied from the reference engine: the three device synchronisations per step of its
+timers (utils/avgmeter.py:273), the >=10 `.item()` calls of its meters and the CPU one-hot of its CE loss.
+`loss_summary` holds device scalars; read them when (and if) you want to log.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import native as nv
+from .distributed import GradAllReducer
+from .losses import GiLtLoss, BodyPartAttentionLoss
+from .metrics import compute_distance_matrix_using_bp_features, evaluate_rank
+from .model import bn_correspondants, PIXELS
+from .optim import FusedAdam
+
+
+class NullWriter:
+    """Absorbs every call the reference's losses/engine make on `writer` (utils/writer.py)."""
+
+    def __getattr__(self, name):
+        return lambda *a, **k: None
+
+
+DEFAULT_WEIGHTS = {'globl': {'id': 1., 'tr': 0.}, 'foreg': {'id': 1., 'tr': 0.}, 'conct': {'id': 1., 'tr': 0.},
+                   'parts': {'id': 0., 'tr': 1.}, 'pixls': {'ce': 0.35}}
+
+
+class ImagePartBasedEngine:
+    def __init__(self, model, optimizer=None, losses_weights=None, loss_name='part_averaged_triplet_loss', margin=0.3,
+                 mask_filtering_training=False, mask_filtering_testing=True, dist_combine_strat='mean',
+                 batch_size_pairwise_dist_matrix=500, test_embeddings=('bn_foreg', 'parts'), scheduler=None, use_gpu=True,
+                 process_group=None, distributed=False, writer=None):
+        self.model = model
+        self.optimizer = optimizer if optimizer is not None else FusedAdam(model)
+        self.scheduler = scheduler
+        self.losses_weights = losses_weights if losses_weights is not None else DEFAULT_WEIGHTS
+        self.parts_num = model.parts_num
+        self.mask_filtering_training = mask_filtering_training
+        self.mask_filtering_testing = mask_filtering_testing
+        self.dist_combine_strat = dist_combine_strat
+        self.batch_size_pairwise_dist_matrix = batch_size_pairwise_dist_matrix
+        self.test_embeddings = list(test_embeddings)
+        self.writer = writer or NullWriter()
+        self.GiLt = GiLtLoss(self.losses_weights, use_visibility_scores=mask_filtering_training, triplet_margin=margin,
+                             loss_name=loss_name, writer=self.writer, use_gpu=use_gpu)
+        self.body_part_attention_loss = BodyPartAttentionLoss(loss_type='cl', use_gpu=use_gpu)
+        self.distributed = distributed
+        self.process_group = process_group
+        self._reducer = None
+
+    # ------------------------------------------------------------------ training
+    def parse_data_for_train(self, data):
+        imgs, masks, pids = data['image'], data.get('mask'), data['pid']
+        dev = next(self.model.parameters()).device
+        imgs = imgs.to(dev, non_blocking=True)
+        pids = pids.to(dev, non_blocking=True)
+        if masks is not None:
+            masks = masks.to(dev, non_blocking=True)
+            assert masks.shape[1] == self.parts_num + 1
+        return imgs, masks, pids, data.get('img_path')
+
+    def forward_backward(self, data):
+        imgs, target_masks, pids, _ = self.parse_data_for_train(data)
+        self.model.train()
+        out = self.model(imgs, external_parts_masks=target_masks)
+        embeddings_dict, visibility_scores_dict, id_cls_scores_dict, pixels_cls_scores, _, _ = out
+        loss, loss_summary = self.combine_losses(visibility_scores_dict, embeddings_dict, id_cls_scores_dict, pids,
+                                                 pixels_cls_scores, target_masks,
+                                                 bpa_weight=self.losses_weights[PIXELS]['ce'])
+        self.optimizer.zero_grad()
+        loss.backward()
+        scale = 1.0
+        if self.distributed:
+            if self._reducer is None:
+                self._reducer = GradAllReducer(self.model.arena()['grad'], self.process_group)
+            self._reducer.start()
+            scale = self._reducer.finish()
+        if isinstance(self.optimizer, FusedAdam):
+            self.optimizer.step(grad_scale=scale)
+        else:
+            if scale != 1.0:
+                self.model.arena()['grad'].mul_(scale)
+            self.optimizer.step()
+        return loss, loss_summary
+
+    def combine_losses(self, visibility_scores_dict, embeddings_dict, id_cls_scores_dict, pids, pixels_cls_scores=None,
+                       target_masks=None, bpa_weight=0):
+        loss, loss_summary = self.GiLt(embeddings_dict, visibility_scores_dict, id_cls_scores_dict, pids)
+        if pixels_cls_scores is not None and target_masks is not None and bpa_weight > 0:
+            # the bilinear resize + argmax of the target masks happens inside the pixel-CE kernel
+            bpa_loss, bpa_summary = self.body_part_attention_loss(pixels_cls_scores, target_masks)
+            loss = loss + bpa_weight * bpa_loss
+            loss_summary = {**loss_summary, **bpa_summary}
+        return loss, loss_summary
+
+    # ------------------------------------------------------------------ evaluation
+    def extract_test_embeddings(self, model_output):
+        embeddings, visibility_scores, _, pixels_cls_scores, _, parts_masks = model_output
+        embs, vis, msk = [], [], []
+        for test_emb in self.test_embeddings:
+            e = embeddings[test_emb]
+            embs.append(e if e.dim() == 3 else e.unsqueeze(1))
+            key = bn_correspondants.get(test_emb, test_emb)
+            v = visibility_scores[key]
+            vis.append(v if v.dim() == 2 else v.unsqueeze(1))
+            pm = parts_masks[key]
+            msk.append(pm if pm.dim() == 4 else pm.unsqueeze(1))
+        return torch.cat(embs, dim=1), torch.cat(vis, dim=1), torch.cat(msk, dim=1), pixels_cls_scores
+
+    @torch.no_grad()
+    def feature_extraction(self, batches):
+        """batches: iterable of dicts with 'image' (+ optional 'mask', 'pid', 'camid')."""
+        self.model.eval()
+        dev = next(self.model.parameters()).device
+        feats, viss, pids, camids = [], [], [], []
+        for data in batches:
+            imgs = data['image'].to(dev)
+            masks = data['mask'].to(dev) if data.get('mask') is not None else None
+            f, v, _, _ = self.extract_test_embeddings(self.model(imgs, external_parts_masks=masks))
+            feats.append(f.clone())
+            viss.append(v.clone())
+            pids.extend(list(data.get('pid', [])))
+            camids.extend(list(data.get('camid', [])))
+        return torch.cat(feats), (torch.cat(viss) if self.mask_filtering_testing else None), pids, camids
+
+    @torch.no_grad()
+    def evaluate(self, qf, gf, q_vis, g_vis, q_pids, g_pids, q_camids, g_camids, dist_metric='euclidean',
+                 normalize_feature=True, max_rank=50):
+        if normalize_feature:
+            qf, gf = F.normalize(qf, p=2, dim=-1), F.normalize(gf, p=2, dim=-1)       # engine.py:558
+        distmat, body_parts_distmat = compute_distance_matrix_using_bp_features(
+            qf, gf, q_vis, g_vis, self.dist_combine_strat, self.batch_size_pairwise_dist_matrix, True, dist_metric)
+        res = evaluate_rank(distmat.numpy(), q_pids, g_pids, q_camids, g_camids, max_rank=max_rank)
+        return res['cmc'], res['mAP'], distmat, body_parts_distmat

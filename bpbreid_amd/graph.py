@@ -1,0 +1,489 @@
+"""Static launch-plan builder for the backbone (host side of csrc/plan.cpp).
+
+The reference executes the backbone as ~650 nn.Module calls per forward and lets autograd replay them
+(torchreid/models/hrnet.py:532-576, resnet.py:342-358).  Here the network is *compiled once* for a
+batch shape into three flat arrays of launch records (train forward, eval forward, backward) over
+pre-allocated NHWC buffers in HBM; running it is one C call (`bpb_plan_run`).
+
+Graph vocabulary (all tensors NHWC fp32):
+    conv      raw convolution output + per-tile BatchNorm partial sums (conv_igemm.hip)
+    fuse      out = act(sum_t affine_t(nearest_up_t(src_t)))  -- BN apply, residual add, HRNet fuse sum, ReLU
+    maxpool   3x3 / stride 2 (ResNet stem)
+    concat    bilinear align_corners upsample of several maps into channel slices of one map (HRNet head)
+"""
+import ctypes as C
+
+import torch
+
+from . import native as nv
+from .native import ConvProb, WgradProb, PackProb, FuseArgs, TermBwdArgs, BilinearArgs, PlanOp, magic, ptr
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _pow2ceil(x):
+    p = 1
+    while p < x:
+        p *= 2
+    return p
+
+
+def _log2(x):
+    return x.bit_length() - 1
+
+
+def choose_tile(n, a, b, pixels):
+    """Factor an M tile of `pixels` (power of two) into TI x TH x TW minimising padded work."""
+    best = None
+    tw = 1
+    while tw <= min(pixels, _pow2ceil(b)):
+        th = 1
+        while th * tw <= pixels and th <= _pow2ceil(a):
+            ti = pixels // (tw * th)
+            cost = (-(-n // ti) * ti) * (-(-a // th) * th) * (-(-b // tw) * tw)
+            key = (cost, -tw, -th)
+            if best is None or key < best[0]:
+                best = (key, ti, th, tw)
+            th *= 2
+        tw *= 2
+    return best[1], best[2], best[3]
+
+
+class Act:
+    """An NHWC activation (and, after backward planning, its gradient) resident in HBM."""
+
+    def __init__(self, net, n, h, w, c, alloc=True):
+        self.N, self.H, self.W, self.C = n, h, w, c
+        self.buf = torch.empty(n, h, w, c, device=net.device, dtype=torch.float32) if alloc else None
+        self.grad = None
+        self.needs_grad = True
+        self._grad_written = False
+
+    def ensure_grad(self, net):
+        if self.grad is None:
+            self.grad = torch.empty_like(self.buf)
+        return self.grad
+
+    def take_acc_flag(self):
+        """0 for the first gradient writer of this tensor in the backward plan, 1 afterwards."""
+        flag = 1 if self._grad_written else 0
+        self._grad_written = True
+        return flag
+
+
+class BNState:
+    """Parameters / buffers of one BatchNorm2d plus the per-step derived vectors."""
+
+    def __init__(self, net, c, weight, bias, running_mean, running_var):
+        self.weight, self.bias, self.running_mean, self.running_var = weight, bias, running_mean, running_var
+        z = lambda: torch.empty(c, device=net.device, dtype=torch.float32)
+        self.scale, self.shift, self.mean, self.invstd, self.c1, self.c2 = z(), z(), z(), z(), z(), z()
+
+
+class ConvNode:
+    def __init__(self, x, y, weight, bias, bn, r, s, stride, pad, cin_real):
+        self.x, self.y, self.weight, self.bias, self.bn = x, y, weight, bias, bn
+        self.R, self.S, self.stride, self.pad, self.cin_real = r, s, stride, pad, cin_real
+
+
+class Net:
+    """Collects ops while the model definition runs, then freezes them into launch plans."""
+
+    def __init__(self, device):
+        self.device = device
+        self.nodes = []            # (kind, payload) in forward order
+        self.keep = []             # ctypes objects / tensors that must outlive the plans
+        self.convs = []
+        self.fwd_train, self.fwd_eval, self.bwd = [], [], []
+        self.debug_convs = []      # (ConvProb, x, packed w, y) -- lets the CPU tests emulate the descriptors
+        self.debug_wgrads = []     # (WgradProb, ConvNode)
+
+    # ------------------------------------------------------------------ graph construction
+    def input_nchw(self, n, c, h, w):
+        """Boundary: the engine hands NCHW images (part_based_engine.py:347-351); internal layout is NHWC4."""
+        self.in_shape = (n, c, h, w)
+        self.in_buf = torch.empty(n, c, h, w, device=self.device, dtype=torch.float32)
+        x = Act(self, n, h, w, 4)
+        x.needs_grad = False
+        self.nodes.append(('input', x))
+        return x
+
+    def conv(self, x, weight, stride, pad, bias=None, bn=None):
+        """weight: OIHW parameter (a view into the flat arena).  Returns the ConvNode (raw output in .y)."""
+        cout, cin_real, r, s = weight.shape
+        assert x.C == (4 if cin_real == 3 else cin_real), (x.C, cin_real)
+        ho = (x.H + 2 * pad - r) // stride + 1
+        wo = (x.W + 2 * pad - s) // stride + 1
+        y = Act(self, x.N, ho, wo, cout)
+        bnst = BNState(self, cout, *bn) if bn is not None else None
+        node = ConvNode(x, y, weight, bias, bnst, r, s, stride, pad, cin_real)
+        self.nodes.append(('conv', node))
+        self.convs.append(node)
+        return node
+
+    def fuse(self, terms, relu):
+        """terms: list of (Act | ConvNode with bn, log2 upsample).  Output has the resolution of term res << up."""
+        t0, up0 = terms[0]
+        a0 = t0.y if isinstance(t0, ConvNode) else t0
+        out = Act(self, a0.N, a0.H << up0, a0.W << up0, a0.C)
+        for t, up in terms:
+            a = t.y if isinstance(t, ConvNode) else t
+            assert (a.H << up, a.W << up, a.C) == (out.H, out.W, out.C), 'fuse: term shape mismatch'
+        self.nodes.append(('fuse', (out, list(terms), bool(relu))))
+        return out
+
+    def maxpool(self, x):
+        ho, wo = (x.H + 2 - 3) // 2 + 1, (x.W + 2 - 3) // 2 + 1
+        y = Act(self, x.N, ho, wo, x.C)
+        idx = torch.empty(x.N, ho, wo, x.C, device=self.device, dtype=torch.uint8)
+        self.nodes.append(('maxpool', (x, y, idx)))
+        return y
+
+    def concat_bilinear(self, srcs):
+        """hrnet.py:568-573: upsample every map to the first one's resolution and concatenate channels."""
+        a0 = srcs[0]
+        out = Act(self, a0.N, a0.H, a0.W, sum(a.C for a in srcs))
+        self.nodes.append(('concat', (out, list(srcs))))
+        return out
+
+    # ------------------------------------------------------------------ plan emission helpers
+    def _op(self, kind, ints=(), floats=(), doubles=(), ptrs=()):
+        op = PlanOp()
+        op.kind = kind
+        for k, v in enumerate(ints):
+            op.i[k] = int(v)
+        for k, v in enumerate(floats):
+            op.f[k] = float(v)
+        for k, v in enumerate(doubles):
+            op.d[k] = float(v)
+        for k, v in enumerate(ptrs):
+            if v is None:
+                op.p[k] = None
+            elif isinstance(v, torch.Tensor):
+                op.p[k] = v.data_ptr()
+            else:
+                op.p[k] = v
+        return op
+
+    def _dev_struct(self, st):
+        """Copy a ctypes struct (array) to device memory; returns (device tensor, host object)."""
+        raw = C.string_at(C.addressof(st), C.sizeof(st))
+        dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        self.keep += [dev, st]
+        return dev
+
+    def conv_problem(self, x_buf, x_dims, w_packed, y_buf, y_dims, a, b, out_map, sa, origin, taps, cin, cout,
+                     bias=None, stats=None, accumulate=0, tile_pixels=256):
+        """Fill one ConvProb.  taps = (Rt, St, dh0, dhs, dw0, dws, w0, wrs, wss); out_map = (osh, osw, ooh, oow)."""
+        n, hi, wi = x_dims
+        ho, wo = y_dims
+        rt, st = taps[0], taps[1]
+        span_h = max(0, rt - 1)
+        span_w = max(0, st - 1)
+        ti, th, tw = choose_tile(n, a, b, tile_pixels)
+        hh = (th - 1) * sa + span_h + 1
+        hw = (tw - 1) * sa + span_w + 1
+        if cin == 4:
+            ck, ld = 4, 4
+        else:
+            ck = 32
+            while cin % ck:
+                ck //= 2
+            assert ck >= 8, 'Cin must be 4 or a multiple of 8'
+            while ck > 8 and ti * hh * hw * (ck + 4) * 4 > 64 * 1024:
+                ck //= 2
+            ld = ck + 4
+        assert ti * hh * hw * ld * 4 <= 160 * 1024, 'conv halo tile exceeds LDS'
+        p = ConvProb()
+        p.x, p.w, p.y = x_buf.data_ptr(), w_packed.data_ptr(), y_buf.data_ptr()
+        p.bias = bias.data_ptr() if bias is not None else None
+        p.stats = None
+        p.N, p.Hi, p.Wi, p.Cin = n, hi, wi, cin
+        p.Ho, p.Wo, p.Cout = ho, wo, cout
+        p.A, p.B = a, b
+        p.osh, p.osw, p.ooh, p.oow = out_map
+        p.sa = sa
+        p.ih0, p.iw0 = origin
+        (p.Rt, p.St, p.dh0, p.dhs, p.dw0, p.dws, p.w0, p.wrs, p.wss) = taps
+        p.lTI, p.lTH, p.lTW = _log2(ti), _log2(th), _log2(tw)
+        p.HH, p.HW, p.CK, p.LD = hh, hw, ck, ld
+        p.tiles_a, p.tiles_b = -(-a // th), -(-b // tw)
+        p.n_mtiles = (-(-n // ti)) * p.tiles_a * p.tiles_b
+        nt = 1 if cout <= 32 else 2
+        p.n_ntiles = -(-cout // (32 * nt))
+        p.blk_begin = 0
+        p.accumulate = accumulate
+        p.magic_hw, p.magic_hh = magic(hw), magic(hh)
+        if stats is not None:
+            st_buf = torch.empty(p.n_mtiles * 2 * cout, device=self.device, dtype=torch.float64)
+            p.stats = st_buf.data_ptr()
+            stats.append(st_buf)
+        self.debug_convs.append((p, x_buf, w_packed, y_buf))
+        return p
+
+    def _emit_conv(self, plans, prob):
+        dev = self._dev_struct(prob)
+        op = self._op(nv.OP_CONV, ints=(1,), ptrs=(dev, C.addressof(prob)))
+        for pl in plans:
+            pl.append(op)
+
+    # ------------------------------------------------------------------ freeze
+    def finalize(self, train_backward=True):
+        """Allocate packed weights / scratch and emit the three launch plans."""
+        dev = self.device
+        # ---- weight packing (one launch for the whole network)
+        packs = (PackProb * len(self.convs))()
+        blk = 0
+        for k, cv in enumerate(self.convs):
+            cout, cin_real, r, s = cv.weight.shape
+            cin_pad = 4 if cin_real == 3 else cin_real
+            t = r * s
+            cv.wf = torch.empty(t * cin_pad * cout, device=dev, dtype=torch.float32)
+            cv.wd = torch.empty(t * cin_pad * cout, device=dev, dtype=torch.float32) if (train_backward and cv.x.needs_grad) else None
+            pk = packs[k]
+            pk.w, pk.wf = cv.weight.data_ptr(), cv.wf.data_ptr()
+            pk.wd = cv.wd.data_ptr() if cv.wd is not None else None
+            pk.Cout, pk.Cin, pk.Cin_pad, pk.T = cout, cin_real, cin_pad, t
+            pk.blk_begin = blk
+            blk += -(-(t * cin_pad * cout) // 256)
+        dpacks = self._dev_struct(packs)
+        pack_op = self._op(nv.OP_PACK, ints=(len(self.convs), blk), ptrs=(dpacks,))
+        self.fwd_train.append(pack_op)
+        self.fwd_eval.append(pack_op)
+        both = (self.fwd_train, self.fwd_eval)
+
+        # ---- forward
+        for kind, pay in self.nodes:
+            if kind == 'input':
+                n, c, h, w = self.in_shape
+                op = self._op(nv.OP_NCHW_TO_NHWC4, ints=(n, c, h, w), ptrs=(self.in_buf, pay.buf))
+                for pl in both:
+                    pl.append(op)
+            elif kind == 'conv':
+                cv = pay
+                x, y = cv.x, cv.y
+                stats = [] if cv.bn is not None else None
+                prob = self.conv_problem(x.buf, (x.N, x.H, x.W), cv.wf, y.buf, (y.H, y.W), y.H, y.W, (1, 1, 0, 0),
+                                         cv.stride, (-cv.pad, -cv.pad), (cv.R, cv.S, 0, 1, 0, 1, 0, cv.S, 1), x.C, y.C,
+                                         bias=cv.bias, stats=stats)
+                self._emit_conv(both, prob)
+                if cv.bn is not None:
+                    bn = cv.bn
+                    cv.stats_buf = stats[0]
+                    count = float(y.N * y.H * y.W)
+                    self.fwd_train.append(self._op(
+                        nv.OP_BN_FINALIZE, ints=(prob.n_mtiles, y.C), floats=(BN_EPS, BN_MOMENTUM), doubles=(count,),
+                        ptrs=(cv.stats_buf, bn.weight, bn.bias, bn.scale, bn.shift, bn.mean, bn.invstd, bn.running_mean,
+                              bn.running_var)))
+                    self.fwd_eval.append(self._op(
+                        nv.OP_BN_EVAL_AFFINE, ints=(y.C,), floats=(BN_EPS,),
+                        ptrs=(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.scale, bn.shift)))
+            elif kind == 'fuse':
+                out, terms, relu = pay
+                fa = FuseArgs()
+                fa.out = out.buf.data_ptr()
+                for k, (t, up) in enumerate(terms):
+                    if isinstance(t, ConvNode):
+                        fa.src[k] = t.y.buf.data_ptr()
+                        fa.scale[k] = t.bn.scale.data_ptr()
+                        fa.shift[k] = t.bn.shift.data_ptr()
+                    else:
+                        fa.src[k] = t.buf.data_ptr()
+                        fa.scale[k] = None
+                        fa.shift[k] = None
+                    fa.up[k] = up
+                fa.nterms = len(terms)
+                fa.N, fa.H, fa.W, fa.C = out.N, out.H, out.W, out.C
+                fa.relu = 1 if relu else 0
+                fa.magic_w, fa.magic_h = magic(out.W), magic(out.H)
+                assert out.N * out.H * out.W * max(out.H, out.W) < (1 << 32)
+                self.keep.append(fa)
+                op = self._op(nv.OP_FUSE_FWD, ptrs=(C.addressof(fa),))
+                for pl in both:
+                    pl.append(op)
+            elif kind == 'maxpool':
+                x, y, idx = pay
+                op = self._op(nv.OP_MAXPOOL_FWD, ints=(x.N, x.H, x.W, x.C), ptrs=(x.buf, y.buf, idx))
+                for pl in both:
+                    pl.append(op)
+            elif kind == 'concat':
+                out, srcs = pay
+                c0 = 0
+                for a in srcs:
+                    ba = self._bilinear_args(a.buf, out.buf, a, out, c0)
+                    op = self._op(nv.OP_BILINEAR_FWD, ptrs=(C.addressof(ba),))
+                    for pl in both:
+                        pl.append(op)
+                    c0 += a.C
+        if train_backward:
+            self._emit_backward()
+        self.plan_train = self._freeze(self.fwd_train)
+        self.plan_eval = self._freeze(self.fwd_eval)
+        self.plan_bwd = self._freeze(self.bwd)
+
+    def _bilinear_args(self, src_buf, dst_buf, a, out, c0, accumulate=0):
+        ba = BilinearArgs()
+        ba.src, ba.dst = src_buf.data_ptr(), dst_buf.data_ptr()
+        ba.N, ba.Hs, ba.Ws, ba.Cs = a.N, a.H, a.W, a.C
+        ba.H, ba.W, ba.Ct, ba.c0 = out.H, out.W, out.C, c0
+        f32 = lambda v: torch.tensor(v, dtype=torch.float32)
+        # ATen computes the scale in fp32: (in - 1) / (out - 1)
+        ba.sh = float(f32(a.H - 1) / f32(out.H - 1)) if out.H > 1 else 0.0
+        ba.sw = float(f32(a.W - 1) / f32(out.W - 1)) if out.W > 1 else 0.0
+        ba.accumulate = accumulate
+        self.keep.append(ba)
+        return ba
+
+    def _freeze(self, ops):
+        arr = (PlanOp * max(1, len(ops)))()
+        for k, op in enumerate(ops):
+            arr[k] = op
+        self.keep.append(arr)
+        return arr, len(ops)
+
+    # ------------------------------------------------------------------ backward plan
+    def _emit_backward(self):
+        bwd = self.bwd
+        # shared split-K workspace for weight gradients (sized while emitting)
+        ws_requests = []
+        for kind, pay in reversed(self.nodes):
+            if kind == 'concat':
+                out, srcs = pay
+                c0 = 0
+                offs = []
+                for a in srcs:
+                    offs.append(c0)
+                    c0 += a.C
+                for a, off in zip(srcs, offs):
+                    a.ensure_grad(self)
+                    ba = self._bilinear_args(a.buf, out.ensure_grad(self), a, out, off, accumulate=a.take_acc_flag())
+                    bwd.append(self._op(nv.OP_BILINEAR_BWD, ptrs=(C.addressof(ba), a.grad)))
+            elif kind == 'fuse':
+                out, terms, relu = pay
+                gout = out.ensure_grad(self)
+                for t, up in terms:
+                    ta = TermBwdArgs()
+                    a = t.y if isinstance(t, ConvNode) else t
+                    ta.dout = gout.data_ptr()
+                    ta.out = out.buf.data_ptr()
+                    ta.N, ta.Hs, ta.Ws, ta.C, ta.up = a.N, a.H, a.W, a.C, up
+                    ta.relu = 1 if relu else 0
+                    ta.magic_w, ta.magic_h = magic(a.W), magic(a.H)
+                    self.keep.append(ta)
+                    if isinstance(t, ConvNode):
+                        bn = t.bn
+                        npix = a.N * a.H * a.W
+                        nblocks = max(1, min(512, npix // 64))
+                        part = torch.empty(nblocks * 2 * a.C, device=self.device, dtype=torch.float64)
+                        self.keep.append(part)
+                        ta.src = a.buf.data_ptr()
+                        ta.mean, ta.invstd, ta.scale = bn.mean.data_ptr(), bn.invstd.data_ptr(), bn.scale.data_ptr()
+                        ta.c1, ta.c2 = bn.c1.data_ptr(), bn.c2.data_ptr()
+                        ta.dsrc = a.ensure_grad(self).data_ptr()
+                        ta.partials = part.data_ptr()
+                        ta.accumulate = a.take_acc_flag()
+                        bwd.append(self._op(nv.OP_TERM_BWD, ints=(1, nblocks), ptrs=(C.addressof(ta),)))
+                        bwd.append(self._op(nv.OP_BN_BWD_FINALIZE, ints=(nblocks, a.C, 0), doubles=(float(npix),),
+                                            ptrs=(part, bn.weight.grad, bn.bias.grad, bn.c1, bn.c2)))
+                        bwd.append(self._op(nv.OP_TERM_BWD, ints=(2, 0), ptrs=(C.addressof(ta),)))
+                    else:
+                        if not a.needs_grad:
+                            continue
+                        ta.dsrc = a.ensure_grad(self).data_ptr()
+                        ta.accumulate = a.take_acc_flag()
+                        bwd.append(self._op(nv.OP_TERM_BWD, ints=(0, 0), ptrs=(C.addressof(ta),)))
+            elif kind == 'maxpool':
+                x, y, idx = pay
+                if x.needs_grad:
+                    x.ensure_grad(self)
+                    bwd.append(self._op(nv.OP_MAXPOOL_BWD, ints=(x.N, x.H, x.W, x.C, x.take_acc_flag()),
+                                        ptrs=(y.ensure_grad(self), idx, x.grad)))
+            elif kind == 'conv':
+                self._emit_conv_backward(pay, ws_requests)
+        # one split-K slab workspace shared by every weight-gradient launch (they run back to back on one stream)
+        ws = torch.empty(max([1] + [r[0] for r in ws_requests]), device=self.device, dtype=torch.float32)
+        self.keep.append(ws)
+        for (elems, prob), (dev_t, _), (red, _) in zip(ws_requests, self._wgrad_descs or [], self._pending_reduce):
+            prob.ws = ws.data_ptr()
+            red.p[0] = ws.data_ptr()
+            raw = C.string_at(C.addressof(prob), C.sizeof(prob))
+            dev_t.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+
+    _wgrad_descs = None
+    _pending_reduce = None
+
+    def _emit_conv_backward(self, cv, ws_requests):
+        if self._wgrad_descs is None:
+            self._wgrad_descs, self._pending_reduce = [], []
+        bwd = self.bwd
+        x, y = cv.x, cv.y
+        gy = y.ensure_grad(self)
+        cout, cin_real, r, s = cv.weight.shape
+        t = r * s
+        # ---- weight gradient: dW[co][ci][r][s] = sum x[.., ci] * dy[.., co]
+        wp = WgradProb()
+        wp.x, wp.dy = x.buf.data_ptr(), gy.data_ptr()
+        wp.N, wp.Hi, wp.Wi, wp.Cin = x.N, x.H, x.W, x.C
+        wp.A, wp.B, wp.Cout = y.H, y.W, cout
+        wp.sa, wp.ih0, wp.iw0 = cv.stride, -cv.pad, -cv.pad
+        wp.T, wp.S = t, s
+        ti, th, tw = choose_tile(x.N, y.H, y.W, 128)
+        wp.lTI, wp.lTH, wp.lTW = _log2(ti), _log2(th), _log2(tw)
+        wp.HH = (th - 1) * cv.stride + r
+        wp.HW = (tw - 1) * cv.stride + s
+        wp.LD = 36
+        wp.tiles_a, wp.tiles_b = -(-y.H // th), -(-y.W // tw)
+        wp.n_mtiles = (-(-x.N // ti)) * wp.tiles_a * wp.tiles_b
+        ntw = 4 if (t == 1 and cout >= 128) else 2 if (t == 1 and cout >= 64) else 1
+        wp.n_citiles = -(-x.C // 32)
+        wp.n_cotiles = -(-cout // (32 * ntw))
+        wp.n_tapgroups = 1 if t == 1 else -(-t // 9)
+        pairs = wp.n_citiles * wp.n_cotiles * wp.n_tapgroups
+        wp.nsplit = max(1, min(wp.n_mtiles, -(-768 // pairs)))
+        wp.blk_begin = 0
+        wp.magic_hw, wp.magic_hh = magic(wp.HW), magic(wp.HH)
+        lds = ((1 << wp.lTI) * wp.HH * wp.HW * wp.LD) * 4 + 128 * 32 * ntw * 4
+        assert lds <= 160 * 1024, 'wgrad tile exceeds LDS'
+        elems = wp.nsplit * t * x.C * cout
+        ws_requests.append((elems, wp))
+        dev = self._dev_struct(wp)
+        self._wgrad_descs.append((dev, wp))
+        self.debug_wgrads.append((wp, cv))
+        bwd.append(self._op(nv.OP_WGRAD, ints=(1,), ptrs=(dev, C.addressof(wp))))
+        # the shared workspace pointer is patched into both records once its size is known (end of _emit_backward)
+        red = self._op(nv.OP_WGRAD_REDUCE, ints=(wp.nsplit, t, x.C, cin_real, cout, 0), ptrs=(None, cv.weight.grad))
+        self._pending_reduce.append((red, wp))
+        bwd.append(red)
+        if cv.bias is not None:
+            raise NotImplementedError('conv bias gradient on the backbone path')
+        # ---- data gradient
+        if not x.needs_grad:
+            return
+        gx = x.ensure_grad(self)
+        acc = x.take_acc_flag()
+        st, pad = cv.stride, cv.pad
+        for ph in range(st):
+            for pw in range(st):
+                a = -(-(x.H - ph) // st)
+                b = -(-(x.W - pw) // st)
+                if a <= 0 or b <= 0:
+                    continue
+                rf, sf = (ph + pad) % st, (pw + pad) % st
+                rt = -(-(r - rf) // st) if rf < r else 0
+                stt = -(-(s - sf) // st) if sf < s else 0
+                dh_abs0 = (ph + pad - rf) // st if rt else 0     # input (dy) row offset of tap i = 0; decreases with i
+                dw_abs0 = (pw + pad - sf) // st if stt else 0
+                ih0 = dh_abs0 - (rt - 1) if rt else 0
+                iw0 = dw_abs0 - (stt - 1) if stt else 0
+                if rt == 0 or stt == 0:
+                    rt = stt = 0
+                taps = (rt, stt, max(rt - 1, 0), -1, max(stt - 1, 0), -1, rf * s + sf, st * s, st)
+                prob = self.conv_problem(gy, (y.N, y.H, y.W), cv.wd, gx, (x.H, x.W), a, b, (st, st, ph, pw), 1,
+                                         (ih0, iw0), taps, cout, x.C, accumulate=acc)
+                self._emit_conv([bwd], prob)
+
+    # ------------------------------------------------------------------ execution
+    def run(self, plan):
+        arr, n = plan
+        nv.call('bpb_plan_run', C.cast(arr, C.c_void_p), n, nv.stream())

@@ -1,0 +1,81 @@
+"""Eval-time part-based distance and ranking with the reference's metric call signatures.
+
+  compute_distance_matrix_using_bp_features(qf, gf, qf_parts_visibility, gf_parts_visibility, dist_combine_strat,
+        batch_size_pairwise_dist_matrix, use_gpu, metric) -> (distmat[Q,G], body_parts_distmat[P,Q,G])   distance.py:87
+  evaluate_rank(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50, eval_metric='default') -> {'cmc','mAP'}   rank.py:173
+The distance runs as one MFMA kernel per gallery shard (csrc/distance.hip); the ranking is the native evaluator of
+csrc/rank.cpp (the wired-up counterpart of the reference's dead Cython module).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import native as nv
+
+
+def _vis_mode(qv, gv):
+    if qv is None or gv is None:
+        return 0
+    return 1 if (qv.dtype is torch.bool and gv.dtype is torch.bool) else 2
+
+
+def compute_distance_matrix_using_bp_features(qf, gf, qf_parts_visibility=None, gf_parts_visibility=None,
+                                              dist_combine_strat='mean', batch_size_pairwise_dist_matrix=5000, use_gpu=True,
+                                              metric='euclidean', device=None, return_device_tensors=False):
+    """`batch_size_pairwise_dist_matrix` is accepted for signature compatibility; 288 GB of HBM holds the whole
+    [P,Q,G] result so the gallery is not chunked (results are identical: the reference's chunking only bounds memory)."""
+    if dist_combine_strat not in ('mean', 'max'):
+        raise ValueError('Body parts distance combination strategy "{}" not supported'.format(dist_combine_strat))
+    if metric not in ('euclidean', 'cosine'):
+        raise ValueError('Unknown distance metric: {}. Please choose either "euclidean" or "cosine"'.format(metric))
+    dev = device or (qf.device if qf.device.type == 'cuda' else torch.device('cuda', torch.cuda.current_device()))
+    nv.init_device()
+    mode = _vis_mode(qf_parts_visibility, gf_parts_visibility)
+    qd = qf.to(dev, torch.float32).contiguous()
+    gd = gf.to(dev, torch.float32).contiguous()
+    q, p, d = qd.shape
+    g = gd.shape[0]
+    qv = qf_parts_visibility.to(dev, torch.float32).contiguous() if mode else None
+    gv = gf_parts_visibility.to(dev, torch.float32).contiguous() if mode else None
+    strat = 1 if (dist_combine_strat == 'max' and mode != 2) else 0      # continuous visibility: mean only (distance.py:200)
+    parts = torch.empty(p, q, g, device=dev, dtype=torch.float32)
+    dist = torch.empty(q, g, device=dev, dtype=torch.float32)
+    qsq = torch.empty(q * p, device=dev, dtype=torch.float32)
+    gsq = torch.empty(g * p, device=dev, dtype=torch.float32)
+    mx = torch.zeros(1, device=dev, dtype=torch.int32)
+    nv.call('bpb_part_distance', qd.data_ptr(), gd.data_ptr(), nv.ptr(qv), nv.ptr(gv), q, g, p, d, mode, strat,
+            1 if metric == 'cosine' else 0, qsq.data_ptr(), gsq.data_ptr(), mx.data_ptr(), parts.data_ptr(), dist.data_ptr(), 1,
+            nv.stream())
+    if return_device_tensors:
+        return dist, parts
+    return dist.cpu(), parts.cpu()
+
+
+def evaluate_rank(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50, eval_metric='default', q_anns=None, g_anns=None,
+                  use_cython=True, return_indices=False, nthreads=None):
+    """market1501 protocol (rank.py:97-159) in native code.  Ties are broken by the lower gallery index (stable)."""
+    if eval_metric != 'default':
+        raise ValueError("Incorrect eval_metric value '{}' (only the default/market1501 protocol is implemented)".format(eval_metric))
+    dm = np.ascontiguousarray(np.asarray(distmat, dtype=np.float32))
+    nq, ng = dm.shape
+    arr = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.int64))
+    qp, gp, qc, gc = arr(q_pids), arr(g_pids), arr(q_camids), arr(g_camids)
+    if ng < max_rank:
+        max_rank = ng
+    cmc = np.zeros(max_rank, dtype=np.float32)
+    mAP = C.c_double(0.0)
+    nvalid = C.c_int(0)
+    idx = np.empty((nq, ng), dtype=np.int32) if return_indices else None
+    pt = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+    nthreads = nthreads or min(64, os.cpu_count() or 1)
+    rc = nv.lib().bpb_eval_rank(pt(dm), pt(qp), pt(gp), pt(qc), pt(gc), nq, ng, max_rank, nthreads, pt(cmc), C.byref(mAP),
+                                C.byref(nvalid), pt(idx))
+    if rc == -2:
+        raise AssertionError('Error: all query identities do not appear in gallery')
+    nv.check(rc)
+    res = {'cmc': cmc, 'mAP': float(mAP.value)}
+    if return_indices:
+        res['indices'] = idx
+    return res

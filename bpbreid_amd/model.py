@@ -1,0 +1,568 @@
+"""BPBreID model on MI355X: same constructor / forward contract / state-dict keys as the reference
+(torchreid/models/bpbreid.py:15-279, registered as 'bpbreid' in torchreid/models/__init__.py:83), executed
+by hand-written HIP kernels through the C-ABI of libbpbreid_hip.so.
+
+    model = bpbreid(num_classes, loss='part_based', pretrained=False, config=cfg)
+    embeddings, visibility_scores, id_cls_scores, pixels_cls_scores, spatial_features, masks = model(imgs, masks)
+
+Execution model (MI355X-first, not a module-by-module translation):
+  * all parameters / gradients / Adam moments live in flat fp32 arenas (one RCCL all-reduce range, one
+    fused Adam launch); the nn.Module tree only names views into them;
+  * the backbone is a static launch plan (graph.Net) run by one C call; activations are NHWC in HBM;
+  * the whole model is ONE autograd node: backward runs the reverse plan and writes parameter
+    gradients straight into the gradient arena (no per-parameter autograd bookkeeping).
+There is no PyTorch/CPU fallback: without the HIP library or a GPU, forward raises.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import native as nv
+from .backbones import build_backbone
+from .graph import Net, BN_EPS, BN_MOMENTUM
+
+GLOBAL, FOREGROUND, BACKGROUND, CONCAT_PARTS, PARTS = 'globl', 'foreg', 'backg', 'conct', 'parts'
+BN_GLOBAL, BN_FOREGROUND, BN_BACKGROUND, BN_CONCAT_PARTS, BN_PARTS = (
+    'bn_globl', 'bn_foreg', 'bn_backg', 'bn_conct', 'bn_parts')
+PIXELS = 'pixls'
+bn_correspondants = {BN_BACKGROUND: BACKGROUND, BN_GLOBAL: GLOBAL, BN_FOREGROUND: FOREGROUND,
+                     BN_CONCAT_PARTS: CONCAT_PARTS, BN_PARTS: PARTS}
+
+
+# ------------------------------------------------------------------------------------------ holders
+class AfterPoolingDimReduceLayer(nn.Module):
+    """bpbreid.py:324-350 (holder): layers.0 Linear(bias), layers.1 BatchNorm1d, ReLU."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.layers = nn.Sequential(nn.Linear(cin, cout), nn.BatchNorm1d(cout), nn.ReLU())
+        nn.init.normal_(self.layers[0].weight, 0, 0.01)      # bpbreid.py:366-369
+        nn.init.constant_(self.layers[0].bias, 0)
+
+
+class PixelToPartClassifier(nn.Module):
+    """bpbreid.py:376-395 (holder)."""
+
+    def __init__(self, c, k):
+        super().__init__()
+        self.bn = nn.BatchNorm2d(c)
+        self.classifier = nn.Conv2d(c, k + 1, 1)
+        nn.init.normal_(self.classifier.weight, 0, 0.001)
+        nn.init.constant_(self.classifier.bias, 0)
+
+
+class BNClassifier(nn.Module):
+    """bpbreid.py:398-425 (holder): BatchNorm1d with frozen bias + bias-free Linear."""
+
+    def __init__(self, cin, ncls):
+        super().__init__()
+        self.bn = nn.BatchNorm1d(cin)
+        self.bn.bias.requires_grad_(False)
+        self.classifier = nn.Linear(cin, ncls, bias=False)
+        nn.init.normal_(self.classifier.weight, 0, 0.001)
+
+
+def _kaiming_backbone(backbone):
+    """hrnet.py:578-586 / resnet.py:323-340 random init."""
+    for m in backbone.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.Linear):
+            nn.init.normal_(m.weight, 0, 0.01)
+            nn.init.constant_(m.bias, 0)
+
+
+# ------------------------------------------------------------------------------------------ small op helpers
+def _f32(*shape, device):
+    return torch.empty(*shape, device=device, dtype=torch.float32)
+
+
+class _Linear:
+    """y[M,N] = x[M,K] . W[N,K]^T (+ b); rows of x / y may be strided (ldx / ldy)."""
+
+    def __init__(self, lin, touched):
+        self.lin, self.touched = lin, touched
+
+    def fwd(self, x_ptr, ldx, m, y_ptr, ldy):
+        w, b = self.lin.weight, self.lin.bias
+        n, k = w.shape
+        self._x, self._ldx, self._m = x_ptr, ldx, m
+        _gemm(x_ptr, ldx, 1, w.data_ptr(), 1, k, y_ptr, ldy, b.data_ptr() if b is not None else None, m, n, k, 0, w.device)
+
+    def bwd(self, dy_ptr, lddy, dx_ptr, lddx, dx_accumulate):
+        w, b = self.lin.weight, self.lin.bias
+        n, k = w.shape
+        m = self._m
+        dev = w.device
+        if dx_ptr is not None:      # dx[M,K] = dy[M,N] . W[N,K]
+            _gemm(dy_ptr, lddy, 1, w.data_ptr(), k, 1, dx_ptr, lddx, None, m, k, n, dx_accumulate, dev)
+        # dW[N,K] = dy^T[N,M] . x[M,K]
+        _gemm(dy_ptr, 1, lddy, self._x, self._ldx, 1, w.grad.data_ptr(), k, None, n, k, m, 0, dev)
+        self.touched.add(id(w))
+        if b is not None:
+            assert lddy == n
+            nv.call('bpb_colsum', dy_ptr, b.grad.data_ptr(), m, n, 0, nv.stream())
+            self.touched.add(id(b))
+
+
+_ws_cache = {}
+
+
+def _gemm(a, sam, sak, b, sbk, sbn, c, ldc, bias, m, n, k, accumulate, device):
+    nsplit = C.c_int(0)
+    nv.call('bpb_gemm', a, sam, sak, b, sbk, sbn, c, ldc, bias, m, n, k, accumulate, None, C.byref(nsplit), None)
+    need = nsplit.value * m * n
+    ws = _ws_cache.get(device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 20), device=device, dtype=torch.float32)
+        _ws_cache[device] = ws
+    nv.call('bpb_gemm', a, sam, sak, b, sbk, sbn, c, ldc, bias, m, n, k, accumulate, ws.data_ptr(), None, nv.stream())
+
+
+class _BN1d:
+    def __init__(self, bn, relu, touched):
+        self.bn, self.relu, self.touched = bn, relu, touched
+        f = bn.num_features
+        self.save_mean = _f32(f, device=bn.weight.device)
+        self.save_invstd = _f32(f, device=bn.weight.device)
+
+    def fwd(self, x_ptr, ldx, rows, y_ptr, ldy, training):
+        bn = self.bn
+        self._x, self._ldx, self._y, self._ldy, self._rows = x_ptr, ldx, y_ptr, ldy, rows
+        nv.call('bpb_bn1d_fwd', x_ptr, ldx, y_ptr, ldy, rows, bn.num_features, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                bn.running_mean.data_ptr(), bn.running_var.data_ptr(), self.save_mean.data_ptr(),
+                self.save_invstd.data_ptr(), BN_EPS, BN_MOMENTUM, 1 if training else 0, 1 if self.relu else 0, nv.stream())
+
+    def bwd(self, dy_ptr, lddy, dx_ptr, lddx):
+        bn = self.bn
+        dbeta = bn.bias.grad.data_ptr() if bn.bias.requires_grad else None
+        nv.call('bpb_bn1d_bwd', dy_ptr, lddy, self._x, self._ldx, self._y, self._ldy, dx_ptr, lddx, self._rows,
+                bn.num_features, bn.weight.data_ptr(), self.save_mean.data_ptr(), self.save_invstd.data_ptr(),
+                bn.weight.grad.data_ptr(), dbeta, 1 if self.relu else 0, 0, nv.stream())
+        self.touched.add(id(bn.weight))
+        if dbeta is not None:
+            self.touched.add(id(bn.bias))
+
+
+# ------------------------------------------------------------------------------------------ the model
+class BPBreID(nn.Module):
+    def __init__(self, num_classes, pretrained, loss, model_cfg, horizontal_stripes=False, **kwargs):
+        super().__init__()
+        m = model_cfg
+        self.model_cfg = m
+        self.num_classes = num_classes
+        self.parts_num = m.masks.parts_num
+        if horizontal_stripes or not m.learnable_attention_enabled:
+            raise NotImplementedError('only the learnable-attention BPBreID path is accelerated (bpbreid.py:146-148)')
+        if m.dim_reduce != 'after_pooling' or m.pooling != 'gwap' or m.normalization != 'identity':
+            raise NotImplementedError("accelerated path: dim_reduce='after_pooling', pooling='gwap', normalization='identity'")
+        if m.test_use_target_segmentation != 'none':
+            raise NotImplementedError("test_use_target_segmentation must be 'none' on the accelerated path")
+        if pretrained:
+            raise NotImplementedError('pretrained backbone download is out of scope; load a state dict instead')
+        self.shared_parts_id_classifier = m.shared_parts_id_classifier
+        self.training_binary_visibility_score = m.training_binary_visibility_score
+        self.testing_binary_visibility_score = m.testing_binary_visibility_score
+        self.backbone_appearance_feature_extractor = build_backbone(
+            m.backbone, num_classes, last_stride=m.last_stride, enable_dim_reduction=False,
+            dim_reduction_channels=m.dim_reduce_output)
+        _kaiming_backbone(self.backbone_appearance_feature_extractor)
+        c = self.backbone_appearance_feature_extractor.feature_dim
+        d = m.dim_reduce_output
+        self.spatial_feature_size, self.dim_reduce_output = c, d
+        self.global_after_pooling_dim_reduce = AfterPoolingDimReduceLayer(c, d)
+        self.foreground_after_pooling_dim_reduce = AfterPoolingDimReduceLayer(c, d)
+        self.background_after_pooling_dim_reduce = AfterPoolingDimReduceLayer(c, d)
+        self.parts_after_pooling_dim_reduce = AfterPoolingDimReduceLayer(c, d)
+        self.pixel_classifier = PixelToPartClassifier(c, self.parts_num)
+        self.global_identity_classifier = BNClassifier(d, num_classes)
+        self.background_identity_classifier = BNClassifier(d, num_classes)
+        self.foreground_identity_classifier = BNClassifier(d, num_classes)
+        self.concat_parts_identity_classifier = BNClassifier(self.parts_num * d, num_classes)
+        if self.shared_parts_id_classifier:
+            self.parts_identity_classifier = BNClassifier(d, num_classes)
+        else:
+            self.parts_identity_classifier = nn.ModuleList([BNClassifier(d, num_classes) for _ in range(self.parts_num)])
+        self._arena = None
+        self._plans = {}
+        self._anchor = None
+
+    # ---------------------------------------------------------------- flat arenas
+    def flatten_parameters(self):
+        """(Re)build the flat parameter / gradient / buffer arenas on the parameters' current device."""
+        params = list(self.parameters())
+        dev = params[0].device
+        if dev.type != 'cuda':
+            raise nv.NativeError('bpbreid_amd runs on an MI355X only: move the model to a GPU (no CPU fallback)')
+        nv.init_device()
+        sizes = [(p.numel() + 3) // 4 * 4 for p in params]          # 16-byte aligned views
+        total = sum(sizes)
+        flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        grad = torch.zeros(total, device=dev, dtype=torch.float32)
+        off = 0
+        self._param_slices = []
+        for p, sz in zip(params, sizes):
+            view = flat[off:off + p.numel()].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = grad[off:off + p.numel()].view(p.shape) if p.requires_grad else None
+            self._param_slices.append((off, p.numel()))
+            off += sz
+        fbufs = [(n, b) for n, b in self.named_buffers() if b.dtype == torch.float32]
+        ibufs = [(n, b) for n, b in self.named_buffers() if b.dtype == torch.int64]
+        bflat = torch.zeros(sum((b.numel() + 3) // 4 * 4 for _, b in fbufs), device=dev, dtype=torch.float32)
+        off = 0
+        for _, b in fbufs:
+            view = bflat[off:off + b.numel()].view(b.shape)
+            view.copy_(b.data)
+            b.data = view
+            off += (b.numel() + 3) // 4 * 4
+        iflat = torch.zeros(max(1, len(ibufs)), device=dev, dtype=torch.int64)
+        for k, (_, b) in enumerate(ibufs):
+            iflat[k] = b.data
+            b.data = iflat[k]
+        self._arena = dict(param=flat, grad=grad, fbuf=bflat, ibuf=iflat, params=params, first_ptr=params[0].data_ptr())
+        self._plans = {}
+        self._anchor = torch.zeros(1, device=dev, requires_grad=True)
+        return self._arena
+
+    def arena(self):
+        a = self._arena
+        if a is None or a['params'][0].data_ptr() != a['first_ptr'] or a['params'][0].device != a['param'].device:
+            a = self.flatten_parameters()
+        return a
+
+    def rebind_grads(self):
+        """Make every parameter's .grad the view into the gradient arena again (after zero_grad(set_to_none))."""
+        a = self.arena()
+        for p, (off, n) in zip(a['params'], self._param_slices):
+            if p.requires_grad:
+                p.grad = a['grad'][off:off + n].view(p.shape)
+
+    # ---------------------------------------------------------------- plans
+    def _plan(self, n, h, w, device):
+        key = (n, h, w)
+        st = self._plans.get(key)
+        if st is None:
+            self.rebind_grads()
+            st = _ModelPlan(self, n, h, w, device)
+            self._plans[key] = st
+        return st
+
+    def forward(self, images, external_parts_masks=None):
+        if images.device.type != 'cuda':
+            raise nv.NativeError('bpbreid_amd.BPBreID.forward needs CUDA/HIP tensors (no CPU fallback)')
+        self.arena()
+        n, _, h, w = images.shape
+        plan = self._plan(n, h, w, images.device)
+        outs = _ModelFn.apply(self._anchor, images, self, plan)
+        return plan.pack_outputs(outs)
+
+
+def bpbreid(num_classes, loss='part_based', pretrained=True, config=None, **kwargs):
+    """Factory with the signature of torchreid/models/bpbreid.py:510-518 (registered name 'bpbreid')."""
+    kwargs.pop('use_gpu', None)
+    return BPBreID(num_classes, pretrained and getattr(config.model, 'pretrained', False), loss, config.model.bpbreid,
+                   **kwargs)
+
+
+OUT_KEYS = ['e_globl', 'e_backg', 'e_foreg', 'e_parts', 'e_bn_globl', 'e_bn_backg', 'e_bn_foreg', 'e_bn_conct',
+            'e_bn_parts', 's_globl', 's_backg', 's_foreg', 's_conct', 's_parts', 'pix', 'feats']
+
+
+class _ModelPlan:
+    """Everything that is fixed for one (batch, height, width): the backbone launch plan and head buffers."""
+
+    def __init__(self, model, n, h, w, device):
+        self.model = model
+        net = Net(device)
+        x = net.input_nchw(n, 3, h, w)
+        feats = model.backbone_appearance_feature_extractor.emit(net, x)
+        net.finalize(train_backward=True)
+        self.net, self.feats = net, feats
+        feats.ensure_grad(net)
+        K, D, Cc = model.parts_num, model.dim_reduce_output, feats.C
+        K1, J, HW, ncls = K + 1, K + 3, feats.H * feats.W, model.num_classes
+        self.N, self.K, self.K1, self.J, self.HW, self.C, self.D, self.ncls = n, K, K1, J, HW, Cc, D, ncls
+        self.Hf, self.Wf = feats.H, feats.W
+        f = lambda *s: _f32(*s, device=device)
+        # pixel classifier / attention
+        self.nstat_blocks = max(1, min(1024, n * HW // 32))
+        self.pix_partials = torch.empty(self.nstat_blocks * 2 * Cc, device=device, dtype=torch.float64)
+        self.pix_scale, self.pix_shift, self.pix_mean, self.pix_invstd = f(Cc), f(Cc), f(Cc), f(Cc)
+        self.pix_wf, self.pix_bf = f(K1, Cc), f(K1)
+        self.logits_pm = f(n, HW, K1)
+        self.scores = f(n, K1, feats.H, feats.W)
+        self.probs = f(n, K1, feats.H, feats.W)
+        self.pm = f(n, J, HW)
+        self.argpart = torch.empty(n, HW, device=device, dtype=torch.uint8)
+        self.argcls = torch.empty(n, HW, device=device, dtype=torch.uint8)
+        self.vis = f(n, K1)
+        self.fgvis = f(n)
+        nch = C.c_int(0)
+        nv.call('bpb_masked_pool', None, None, None, n, HW, Cc, J, C.byref(nch), None)
+        self.nchunks = nch.value
+        self.pool_part = f(n * self.nchunks * max(J, K1) * Cc)
+        self.pooled = f(n, J, Cc)
+        self.zinv = f(n, J)
+        # dense stack buffers
+        self.lin_g, self.lin_f, self.lin_b, self.lin_p = f(n, D), f(n, D), f(n, D), f(n, K, D)
+        # backward scratch
+        self.g_pooled = f(n, J, Cc)
+        self.gp = f(n, J)
+        self.Dd = f(n, HW, K1 + 1)
+        self.dlogit = f(n, K1, HW)
+        self.k1, self.k2 = f(Cc), f(Cc)
+        m = model
+        self.touched = set()
+        T = self.touched
+        self.backbone_touched = set()
+        for cv in net.convs:
+            self.backbone_touched.add(id(cv.weight))
+            if cv.bn is not None:
+                self.backbone_touched.update((id(cv.bn.weight), id(cv.bn.bias)))
+        _Lin = lambda l: _Linear(l, T)
+        _Bn = lambda b, r: _BN1d(b, r, T)
+        self.dr = {'g': (_Lin(m.global_after_pooling_dim_reduce.layers[0]), _Bn(m.global_after_pooling_dim_reduce.layers[1], True)),
+                   'f': (_Lin(m.foreground_after_pooling_dim_reduce.layers[0]), _Bn(m.foreground_after_pooling_dim_reduce.layers[1], True)),
+                   'b': (_Lin(m.background_after_pooling_dim_reduce.layers[0]), _Bn(m.background_after_pooling_dim_reduce.layers[1], True))}
+        self.dr_p_lin = [_Lin(m.parts_after_pooling_dim_reduce.layers[0]) for _ in range(K)]
+        self.dr_p_bn = _Bn(m.parts_after_pooling_dim_reduce.layers[1], True)
+        self.cls = {'g': (_Bn(m.global_identity_classifier.bn, False), _Lin(m.global_identity_classifier.classifier)),
+                    'b': (_Bn(m.background_identity_classifier.bn, False), _Lin(m.background_identity_classifier.classifier)),
+                    'f': (_Bn(m.foreground_identity_classifier.bn, False), _Lin(m.foreground_identity_classifier.classifier)),
+                    'c': (_Bn(m.concat_parts_identity_classifier.bn, False), _Lin(m.concat_parts_identity_classifier.classifier))}
+        if m.shared_parts_id_classifier:
+            self.cls_p = [(_Bn(m.parts_identity_classifier.bn, False), _Lin(m.parts_identity_classifier.classifier))]
+        else:
+            self.cls_p = [(_Bn(pc.bn, False), _Lin(pc.classifier)) for pc in m.parts_identity_classifier]
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, images, training):
+        m, net, s = self.model, self.net, nv.stream
+        n, K, K1, J, HW, Cc, D, ncls = self.N, self.K, self.K1, self.J, self.HW, self.C, self.D, self.ncls
+        dev = images.device
+        net.in_buf.copy_(images)                       # boundary copy (same device); H2D is the caller's business
+        net.run(net.plan_train if training else net.plan_eval)
+        if training:
+            m._arena['ibuf'] += 1                      # every BatchNorm's num_batches_tracked
+        x = self.feats.buf
+        pc = m.pixel_classifier
+        if training:
+            nv.call('bpb_channel_stats', x.data_ptr(), n * HW, Cc, self.pix_partials.data_ptr(), self.nstat_blocks, s())
+            nv.call('bpb_bn_finalize', self.pix_partials.data_ptr(), self.nstat_blocks, Cc, float(n * HW),
+                    pc.bn.weight.data_ptr(), pc.bn.bias.data_ptr(), BN_EPS, BN_MOMENTUM, self.pix_scale.data_ptr(),
+                    self.pix_shift.data_ptr(), self.pix_mean.data_ptr(), self.pix_invstd.data_ptr(),
+                    pc.bn.running_mean.data_ptr(), pc.bn.running_var.data_ptr(), s())
+        else:
+            nv.call('bpb_bn_eval_affine', Cc, pc.bn.weight.data_ptr(), pc.bn.bias.data_ptr(), pc.bn.running_mean.data_ptr(),
+                    pc.bn.running_var.data_ptr(), BN_EPS, self.pix_scale.data_ptr(), self.pix_shift.data_ptr(), s())
+        nv.call('bpb_fold_bn', pc.classifier.weight.data_ptr(), pc.classifier.bias.data_ptr(), self.pix_scale.data_ptr(),
+                self.pix_shift.data_ptr(), self.pix_wf.data_ptr(), self.pix_bf.data_ptr(), K1, Cc, s())
+        nv.call('bpb_pixel_dots', x.data_ptr(), self.pix_wf.data_ptr(), 0, self.pix_bf.data_ptr(), self.logits_pm.data_ptr(),
+                n, HW, Cc, K1, s())
+        nv.call('bpb_softmax_masks', self.logits_pm.data_ptr(), self.scores.data_ptr(), self.probs.data_ptr(),
+                self.pm.data_ptr(), self.argpart.data_ptr(), self.argcls.data_ptr(), n, HW, K1, s())
+        binary = m.training_binary_visibility_score if training else m.testing_binary_visibility_score
+        self.binary = bool(binary)
+        nv.call('bpb_visibility', self.probs.data_ptr(), self.argcls.data_ptr(), self.vis.data_ptr(), self.fgvis.data_ptr(),
+                n, HW, K1, 1 if binary else 0, s())
+        nv.call('bpb_masked_pool', x.data_ptr(), self.pm.data_ptr(), self.pool_part.data_ptr(), n, HW, Cc, J, None, s())
+        nv.call('bpb_pool_finalize', self.pool_part.data_ptr(), self.pm.data_ptr(), self.pooled.data_ptr(),
+                self.zinv.data_ptr(), n, self.nchunks, J, HW, Cc, s())
+        # ---- after-pooling dim reduce (Linear + BN1d + ReLU); pooled rows: 0 global, 1 fg, 2 bg, 3.. parts
+        o = {}
+        f = lambda *sh: _f32(*sh, device=dev)
+        pp = self.pooled.data_ptr()
+        for key, row, lin_buf in (('g', 0, self.lin_g), ('f', 1, self.lin_f), ('b', 2, self.lin_b)):
+            lin, bn = self.dr[key]
+            lin.fwd(pp + row * Cc * 4, J * Cc, n, lin_buf.data_ptr(), D)
+            out = f(n, D)
+            bn.fwd(lin_buf.data_ptr(), D, n, out.data_ptr(), D, training)
+            o[key] = out
+        for k in range(K):
+            self.dr_p_lin[k].fwd(pp + (3 + k) * Cc * 4, J * Cc, n, self.lin_p.data_ptr() + k * D * 4, K * D)
+        o['p'] = f(n, K, D)
+        self.dr_p_bn.fwd(self.lin_p.data_ptr(), D, n * K, o['p'].data_ptr(), D, training)
+        # ---- BN-neck identity classifiers
+        e = {}
+        for key, src, width in (('g', o['g'], D), ('b', o['b'], D), ('f', o['f'], D), ('c', o['p'], K * D)):
+            bn, lin = self.cls[key]
+            feat, sc = f(n, width), f(n, ncls)
+            bn.fwd(src.data_ptr(), width, n, feat.data_ptr(), width, training)
+            lin.fwd(feat.data_ptr(), width, n, sc.data_ptr(), ncls)
+            e[key] = (feat, sc)
+        bn_p, s_p = f(n, K, D), f(n, K, ncls)
+        if m.shared_parts_id_classifier:
+            bn, lin = self.cls_p[0]
+            bn.fwd(o['p'].data_ptr(), D, n * K, bn_p.data_ptr(), D, training)
+            lin.fwd(bn_p.data_ptr(), D, n * K, s_p.data_ptr(), ncls)
+        else:
+            for k, (bn, lin) in enumerate(self.cls_p):
+                bn.fwd(o['p'].data_ptr() + k * D * 4, K * D, n, bn_p.data_ptr() + k * D * 4, K * D, training)
+                lin.fwd(bn_p.data_ptr() + k * D * 4, K * D, n, s_p.data_ptr() + k * ncls * 4, K * ncls)
+        self.o, self.e = o, e
+        self.bn_p, self.s_p = bn_p, s_p
+        feats_nchw = self.feats.buf.permute(0, 3, 1, 2)          # logical NCHW view of the NHWC buffer (no copy)
+        return (o['g'], o['b'], o['f'], o['p'], e['g'][0], e['b'][0], e['f'][0], e['c'][0], bn_p,
+                e['g'][1], e['b'][1], e['f'][1], e['c'][1], s_p, self.scores, feats_nchw)
+
+    def pack_outputs(self, outs):
+        n, K = self.N, self.K
+        (g, b, fo, p, bg_, bb_, bf_, bc_, bp_, sg, sb, sf, sc, sp, pix, feats) = outs
+        c = p.flatten(1, 2)                                      # bpbreid.py:212 (autograd view of the parts embeddings)
+        emb = {GLOBAL: g, BACKGROUND: b, FOREGROUND: fo, CONCAT_PARTS: c, PARTS: p, BN_GLOBAL: bg_, BN_BACKGROUND: bb_,
+               BN_FOREGROUND: bf_, BN_CONCAT_PARTS: bc_, BN_PARTS: bp_}
+        if self.binary:
+            vis = self.vis > 0.5
+            fgvis = self.fgvis > 0.5
+        else:
+            vis, fgvis = self.vis.clone(), self.fgvis.clone()
+        visd = {GLOBAL: torch.ones_like(fgvis), BACKGROUND: vis[:, 0], FOREGROUND: fgvis, CONCAT_PARTS: fgvis,
+                PARTS: vis[:, 1:]}
+        ids = {GLOBAL: sg, BACKGROUND: sb, FOREGROUND: sf, CONCAT_PARTS: sc, PARTS: sp}
+        Hf, Wf = self.Hf, self.Wf
+        pm = self.pm.view(n, self.J, Hf, Wf)
+        fg = pm[:, 1]
+        masks = {GLOBAL: pm[:, 0], BACKGROUND: self.probs[:, 0], FOREGROUND: fg, CONCAT_PARTS: fg, PARTS: self.probs[:, 1:]}
+        return emb, visd, ids, pix, feats, masks
+
+    # ---------------------------------------------------------------- backward
+    def backward(self, grads):
+        """grads: tuple aligned with OUT_KEYS (None where no gradient flows)."""
+        m, net, s = self.model, self.net, nv.stream
+        n, K, K1, J, HW, Cc, D, ncls = self.N, self.K, self.K1, self.J, self.HW, self.C, self.D, self.ncls
+        dev = self.pooled.device
+        g = dict(zip(OUT_KEYS, grads))
+        f = lambda *sh: _f32(*sh, device=dev)
+
+        def init_grad(ext, *shape):
+            buf = f(*shape)
+            if ext is None:
+                nv.call('bpb_fill', buf.data_ptr(), 0.0, buf.numel(), s())
+            else:
+                ext = ext.contiguous()
+                nv.call('bpb_scale', ext.data_ptr(), None, 1.0, buf.data_ptr(), buf.numel(), 0, s())
+            return buf
+
+        def add_grad(buf, ext):
+            if ext is not None:
+                ext = ext.contiguous()
+                nv.call('bpb_scale', ext.data_ptr(), None, 1.0, buf.data_ptr(), buf.numel(), 1, s())
+
+        # Which branches received a gradient?  Branches without one are skipped so that their parameters keep
+        # "grad is None" semantics (torch.optim.Adam then neither decays nor moves them -- SURVEY.md section 5).
+        self.touched.clear()
+        has = {'g': any(g[k] is not None for k in ('e_globl', 'e_bn_globl', 's_globl')),
+               'b': any(g[k] is not None for k in ('e_backg', 'e_bn_backg', 's_backg')),
+               'f': any(g[k] is not None for k in ('e_foreg', 'e_bn_foreg', 's_foreg')),
+               'p': any(g[k] is not None for k in ('e_parts', 'e_bn_parts', 's_parts', 'e_bn_conct', 's_conct'))}
+        d_o = {'g': init_grad(g['e_globl'], n, D) if has['g'] else None,
+               'b': init_grad(g['e_backg'], n, D) if has['b'] else None,
+               'f': init_grad(g['e_foreg'], n, D) if has['f'] else None,
+               'p': init_grad(g['e_parts'], n, K, D) if has['p'] else None}
+        # ---- identity classifiers
+        for key, gs, gf, width in (('g', g['s_globl'], g['e_bn_globl'], D), ('b', g['s_backg'], g['e_bn_backg'], D),
+                                   ('f', g['s_foreg'], g['e_bn_foreg'], D), ('c', g['s_conct'], g['e_bn_conct'], K * D)):
+            if gs is None and gf is None:
+                continue
+            bn, lin = self.cls[key]
+            dfeat = init_grad(gf, n, width)
+            if gs is not None:
+                gs = gs.contiguous()
+                lin.bwd(gs.data_ptr(), ncls, dfeat.data_ptr(), width, 1)
+            dx = f(n, width)
+            bn.bwd(dfeat.data_ptr(), width, dx.data_ptr(), width)
+            tgt = d_o['p'] if key == 'c' else d_o[key]
+            nv.call('bpb_scale', dx.data_ptr(), None, 1.0, tgt.data_ptr(), dx.numel(), 1, s())
+        if g['s_parts'] is not None or g['e_bn_parts'] is not None:
+            dfeat = init_grad(g['e_bn_parts'], n, K, D)
+            gs = g['s_parts'].contiguous() if g['s_parts'] is not None else None
+            dxp = f(n, K, D)
+            if m.shared_parts_id_classifier:
+                bn, lin = self.cls_p[0]
+                if gs is not None:
+                    lin.bwd(gs.data_ptr(), ncls, dfeat.data_ptr(), D, 1)
+                bn.bwd(dfeat.data_ptr(), D, dxp.data_ptr(), D)
+            else:
+                for k, (bn, lin) in enumerate(self.cls_p):
+                    if gs is not None:
+                        lin.bwd(gs.data_ptr() + k * ncls * 4, K * ncls, dfeat.data_ptr() + k * D * 4, K * D, 1)
+                    bn.bwd(dfeat.data_ptr() + k * D * 4, K * D, dxp.data_ptr() + k * D * 4, K * D)
+            nv.call('bpb_scale', dxp.data_ptr(), None, 1.0, d_o['p'].data_ptr(), dxp.numel(), 1, s())
+        # ---- dim-reduce stacks -> gradient of the pooled rows (rows of skipped branches are zero)
+        gpool = self.g_pooled
+        gp_ptr = gpool.data_ptr()
+        nv.call('bpb_fill', gp_ptr, 0.0, gpool.numel(), s())
+        for key, row in (('g', 0), ('f', 1), ('b', 2)):
+            if not has[key]:
+                continue
+            lin, bn = self.dr[key]
+            dlin = f(n, D)
+            bn.bwd(d_o[key].data_ptr(), D, dlin.data_ptr(), D)
+            lin.bwd(dlin.data_ptr(), D, gp_ptr + row * Cc * 4, J * Cc, 0)
+        if has['p']:
+            dlin_p = f(n, K, D)
+            self.dr_p_bn.bwd(d_o['p'].data_ptr(), D, dlin_p.data_ptr(), D)
+            plin = m.parts_after_pooling_dim_reduce.layers[0]
+            w = plin.weight
+            nn_, kk = w.shape
+            for k in range(K):       # the K part GEMMs share one Linear: dW accumulates over k
+                lin = self.dr_p_lin[k]
+                _gemm(dlin_p.data_ptr() + k * D * 4, K * D, 1, w.data_ptr(), kk, 1, gp_ptr + (3 + k) * Cc * 4, J * Cc, None, n,
+                      kk, nn_, 0, dev)
+                _gemm(dlin_p.data_ptr() + k * D * 4, 1, K * D, lin._x, lin._ldx, 1, w.grad.data_ptr(), kk, None, nn_, kk, n,
+                      1 if k > 0 else 0, dev)
+            nv.call('bpb_colsum', dlin_p.data_ptr(), plin.bias.grad.data_ptr(), n * K, D, 0, s())
+            self.touched.update((id(w), id(plin.bias)))
+        # ---- attention head backward
+        x = self.feats.buf
+        pc = m.pixel_classifier
+        nv.call('bpb_rowdot', gpool.data_ptr(), self.pooled.data_ptr(), self.gp.data_ptr(), n * J, Cc, s())
+        nv.call('bpb_pixel_dots', x.data_ptr(), gp_ptr + Cc * 4, J * Cc, None, self.Dd.data_ptr(), n, HW, Cc, K1 + 1, s())
+        gpix = g['pix'].contiguous() if g['pix'] is not None else None
+        nv.call('bpb_head_bwd_dlogits', self.Dd.data_ptr(), self.probs.data_ptr(), self.argpart.data_ptr(), self.zinv.data_ptr(),
+                self.gp.data_ptr(), gpix.data_ptr() if gpix is not None else None, self.dlogit.data_ptr(), n, HW, K1, s())
+        nv.call('bpb_masked_pool', x.data_ptr(), self.dlogit.data_ptr(), self.pool_part.data_ptr(), n, HW, Cc, K1, None, s())
+        nv.call('bpb_head_bwd_params', self.pool_part.data_ptr(), n * self.nchunks, self.dlogit.data_ptr(), n, HW, K1, Cc,
+                pc.classifier.weight.data_ptr(), pc.bn.weight.data_ptr(), pc.bn.bias.data_ptr(), self.pix_mean.data_ptr(),
+                self.pix_invstd.data_ptr(), pc.classifier.weight.grad.data_ptr(), pc.classifier.bias.grad.data_ptr(),
+                pc.bn.weight.grad.data_ptr(), pc.bn.bias.grad.data_ptr(), self.k1.data_ptr(), self.k2.data_ptr(), 0, s())
+        gfe = g['feats']
+        if gfe is not None:
+            raise NotImplementedError('external gradient on spatial_features')
+        nv.call('bpb_head_bwd_dx', x.data_ptr(), gpool.data_ptr(), self.pm.data_ptr(), self.zinv.data_ptr(),
+                self.dlogit.data_ptr(), pc.classifier.weight.data_ptr(), pc.bn.weight.data_ptr(), self.pix_mean.data_ptr(),
+                self.pix_invstd.data_ptr(), self.k1.data_ptr(), self.k2.data_ptr(), self.feats.grad.data_ptr(), n, HW, Cc, K1,
+                0, s())
+        net.run(net.plan_bwd)
+        self.touched.update(id(t) for t in (pc.classifier.weight, pc.classifier.bias, pc.bn.weight, pc.bn.bias))
+        self.touched |= self.backbone_touched
+        for p in m._arena['params']:          # parameters that did not take part keep grad None (torch semantics)
+            if id(p) not in self.touched:
+                p.grad = None
+
+
+class _ModelFn(torch.autograd.Function):
+    """The whole BPBreID forward/backward as one autograd node over the flat arenas."""
+
+    @staticmethod
+    def forward(ctx, anchor, images, model, plan):
+        training = model.training
+        ctx.set_materialize_grads(False)       # unused outputs must arrive as None, not zeros
+        outs = plan.forward(images, training)
+        ctx.plan = plan
+        ctx.training = training
+        ctx.mark_non_differentiable(outs[-1])
+        return outs
+
+    @staticmethod
+    def backward(ctx, *grads):
+        if not ctx.training:
+            raise RuntimeError('bpbreid_amd: backward through an eval-mode forward is not supported')
+        ctx.plan.model.rebind_grads()
+        ctx.plan.backward(grads)
+        return None, None, None, None

@@ -1,0 +1,272 @@
+/* bpbreid_hip.h -- C ABI of libbpbreid_hip.so: the MI355X (gfx950) hot path of BPBReID.
+ *
+ * Every entry point replaces an op (or fused group of ops) that the reference implementation
+ * (VlSomers/bpbreid, paths relative to its repository root) dispatches through PyTorch/ATen; the reference file:line
+ * each one stands in for is given next to the declaration.  The reference has no FFI of its own (SURVEY.md section
+ * 8b): this header is the binding surface a maintainer would call from Python (ctypes).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.  All device pointers are HIP device memory owned by the
+ *     caller (e.g. the PyTorch caching allocator); the library allocates nothing persistent and keeps no state.
+ *   - Every function enqueues on the given hipStream_t and returns without synchronising.
+ *   - Return 0 on success; < 0 for an argument error detected before launch; > 0 is a hipError_t.
+ *     bpb_last_error() returns a thread-local description.
+ *   - Activations are fp32 NHWC ([N][H][W][C], C a multiple of 4, 16-byte aligned).  "NCHW" is said explicitly.
+ */
+#ifndef BPBREID_HIP_H
+#define BPBREID_HIP_H
+
+#include <stdint.h>
+#if defined(__HIPCC__) || defined(__HIP__)
+#include <hip/hip_runtime.h>
+#else
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BPB_MAX_TERMS 4
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Descriptor of one implicit-GEMM convolution problem (device resident; a launch takes an array = "grouped launch").
+ *   y[n, a*osh+ooh, b*osw+oow, :] (+)= sum_t x[n, a*sa + dh_t + ih0, b*sa + dw_t + iw0, :] . W_t
+ * covers forward convolutions (any R, S, stride, pad), stride-1 data gradients and the parity classes of strided
+ * data gradients.  W is pre-packed [tap][Cin/4][Cout][4] by bpb_pack_weights.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct BpbConvProb {
+    const float* x;
+    const float* w;
+    float* y;
+    const float* bias;      // optional [Cout]
+    double* stats;          // optional [n_mtiles][2][Cout] per-tile (sum, sumsq) partials for BatchNorm
+    int N, Hi, Wi, Cin;     // input tensor dims (Cin multiple of 8, or == 4)
+    int Ho, Wo, Cout;       // output tensor dims
+    int A, B;               // logical output grid handled by this problem
+    int osh, osw, ooh, oow; // logical -> output coordinate map
+    int sa;                 // input step per logical step
+    int ih0, iw0;           // input origin
+    // regular tap grid: tap (i, j), i < Rt, j < St reads input offset (dh0 + dhs*i, dw0 + dws*j) >= 0 relative to
+    // (ih0, iw0) and uses packed-weight slice w0 + wrs*i + wss*j.  Covers full filters (forward, stride-1 dgrad)
+    // and the per-parity tap subsets of strided dgrad without any table lookup in the inner loop.
+    int Rt, St, dh0, dhs, dw0, dws, w0, wrs, wss;
+    int lTI, lTH, lTW;      // log2 of the M-tile factorisation TI x TH x TW (= 256 pixels)
+    int HH, HW;             // halo tile dims
+    int CK, LD;             // channel chunk staged per pass and LDS row pitch (floats)
+    int tiles_a, tiles_b, n_mtiles, n_ntiles;
+    int blk_begin;          // first blockIdx of this problem inside a grouped launch
+    int accumulate;         // y += result
+    unsigned magic_hw, magic_hh;   // ceil(2^32/d) for d = HW, HH (staging index split without idiv)
+} BpbConvProb;
+
+/* weight-gradient problem: dW[t][ci][co] = sum_{n,a,b} x[n, a*sa + t/S + ih0, b*sa + t%S + iw0, ci] * dy[n,a,b,co] */
+typedef struct BpbWgradProb {
+    const float* x;        // NHWC input of the conv
+    const float* dy;       // NHWC grad of the conv output [N][A][B][Cout]
+    float* ws;             // partial slabs [nsplit][T][Cin][Cout]
+    int N, Hi, Wi, Cin;
+    int A, B, Cout;
+    int sa, ih0, iw0;
+    int T, S;              // total taps (R*S) and filter width; tap t reads input offset (t / S, t % S)
+    int lTI, lTH, lTW;     // 128-pixel tile factorisation
+    int HH, HW, LD;
+    int tiles_a, tiles_b, n_mtiles;
+    int n_citiles, n_cotiles, n_tapgroups, nsplit;
+    int blk_begin;
+    unsigned magic_hw, magic_hh;
+} BpbWgradProb;
+
+/* one convolution's weights for bpb_pack_weights: w is OIHW (the state-dict layout) */
+typedef struct BpbPackProb {
+    const float* w;   // OIHW
+    float* wf;
+    float* wd;
+    int Cout, Cin, Cin_pad, T;
+    int blk_begin;
+} BpbPackProb;
+
+/* out = act(sum_t affine_t(nearest_up_t(src_t))) */
+typedef struct BpbFuseArgs {
+    float* out;                         // [N][H][W][C]
+    const float* src[BPB_MAX_TERMS];    // term t: [N][H>>up][W>>up][C]
+    const float* scale[BPB_MAX_TERMS];  // nullptr -> identity term
+    const float* shift[BPB_MAX_TERMS];
+    int up[BPB_MAX_TERMS];              // log2 nearest-upsample factor
+    int nterms;
+    int N, H, W, C;
+    int relu;
+    unsigned magic_w, magic_h;          // ceil(2^32 / W), ceil(2^32 / H)
+} BpbFuseArgs;
+
+/* backward of one term of the fused sum */
+typedef struct BpbTermBwdArgs {
+    const float* dout;      // [N][H][W][C] gradient wrt `out`
+    const float* out;       // forward output (ReLU mask), may be nullptr when relu == 0
+    const float* src;       // forward input of the term (conv raw output) [N][Hs][Ws][C]; BN terms only
+    const float* mean;      // BN terms: saved batch mean / invstd / scale(gamma*invstd)
+    const float* invstd;
+    const float* scale;
+    const float* c1;        // BN apply: per-channel sum(G)/M and sum(G*xhat)/M
+    const float* c2;
+    float* dsrc;            // gradient wrt src
+    double* partials;       // BN reduce: [nblocks][2][C]
+    int N, Hs, Ws, C, up;   // src spatial dims; out dims are Hs<<up, Ws<<up
+    int relu, accumulate;
+    unsigned magic_w, magic_h;   // for Ws, Hs
+} BpbTermBwdArgs;
+
+/* bilinear (align_corners) upsample of one map into a channel slice of the concatenated map */
+typedef struct BpbBilinearArgs {
+    const float* src;   // [N][Hs][Ws][Cs]
+    float* dst;         // [N][H][W][Ct], written at channel offset c0
+    int N, Hs, Ws, Cs, H, W, Ct, c0;
+    float sh, sw;       // (Hs-1)/(H-1), (Ws-1)/(W-1) computed in fp32 like ATen
+    int accumulate;     // backward only: dsrc += ...
+} BpbBilinearArgs;
+
+/* launch-plan records executed by bpb_plan_run (slot meaning per kind: see csrc/plan.cpp) */
+typedef enum BpbOpKind {
+    BPB_OP_CONV = 0,
+    BPB_OP_WGRAD = 1,
+    BPB_OP_WGRAD_REDUCE = 2,
+    BPB_OP_PACK = 3,
+    BPB_OP_BN_FINALIZE = 4,
+    BPB_OP_BN_EVAL_AFFINE = 5,
+    BPB_OP_FUSE_FWD = 6,
+    BPB_OP_TERM_BWD = 7,
+    BPB_OP_BN_BWD_FINALIZE = 8,
+    BPB_OP_NCHW_TO_NHWC4 = 9,
+    BPB_OP_MAXPOOL_FWD = 10,
+    BPB_OP_MAXPOOL_BWD = 11,
+    BPB_OP_BILINEAR_FWD = 12,
+    BPB_OP_BILINEAR_BWD = 13,
+    BPB_OP_FILL = 14,
+    BPB_OP_CHANNEL_STATS = 15,
+} BpbOpKind;
+
+// generic op record; slot meaning per kind is documented next to each case
+typedef struct BpbPlanOp {
+    int kind;
+    int i[11];
+    float f[4];
+    double d[2];
+    void* p[12];
+} BpbPlanOp;
+
+/* ---- error reporting ------------------------------------------------------------------------------------------ */
+const char* bpb_last_error(void);
+int bpb_conv_init(void);     /* once per process: allow 160 KiB of dynamic LDS for the conv kernels           */
+int bpb_head_init(void);     /* once per process: same for the pixel-dots kernels                              */
+
+/* ---- backbone convolutions: nn.Conv2d forward / backward on the path ---------------------------------------------
+ * torchreid/models/hrnet.py:61-64 (conv3x3), :104-110 (bottleneck 1x1/3x3/1x1), :184,223 (1x1 downsample / fuse up),
+ * :240-250 (strided 3x3 fuse down), :319-323 (stem), :459-481 (transitions); torchreid/models/resnet.py:31-49,211-216.
+ * bpb_conv_igemm = aten::conv2d forward and conv backward-input; bpb_conv_wgrad + bpb_wgrad_reduce = backward-weight. */
+int bpb_conv_igemm(const BpbConvProb* d_probs, const BpbConvProb* h_probs, int nprobs, hipStream_t stream);
+int bpb_conv_wgrad(const BpbWgradProb* d_probs, const BpbWgradProb* h_probs, int nprobs, hipStream_t stream);
+int bpb_wgrad_reduce(const float* ws, float* dw, int nsplit, int T, int Cin, int Cin_real, int Cout, int accumulate,
+                     hipStream_t stream);
+int bpb_pack_weights(const BpbPackProb* d_probs, int nprobs, int total_blocks, hipStream_t stream);
+
+/* ---- BatchNorm2d + residual / fuse sums + nearest upsample + ReLU --------------------------------------------------
+ * hrnet.py:73-76,84-96 (BasicBlock), :117-137 (Bottleneck), :229-231 (BN + nn.Upsample nearest), :269-277 (fuse sum +
+ * ReLU), :533-538 (stem BN/ReLU); resnet.py:133-154.  Training statistics follow nn.BatchNorm2d (momentum 0.1,
+ * eps 1e-5, unbiased running variance). */
+int bpb_bn_finalize(const double* partials, int nparts, int C, double count, const float* gamma, const float* beta,
+                    float eps, float momentum, float* scale, float* shift, float* mean, float* invstd,
+                    float* running_mean, float* running_var, hipStream_t stream);
+int bpb_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* scale, float* shift, hipStream_t stream);
+int bpb_channel_stats(const float* x, long P, int C, double* partials, int nblocks, hipStream_t stream);
+int bpb_fuse_fwd(const BpbFuseArgs* a, hipStream_t stream);
+int bpb_term_bwd(const BpbTermBwdArgs* a, int mode, int nblocks, hipStream_t stream);
+int bpb_bn_bwd_finalize(const double* partials, int nparts, int C, double count, float* dgamma, float* dbeta,
+                        int accumulate, float* c1, float* c2, hipStream_t stream);
+
+/* ---- layout / resampling ---------------------------------------------------------------------------------------
+ * NCHW boundary of engine/image/part_based_engine.py:347-351; resnet.py:217,346 (max pool);
+ * hrnet.py:568-573 (F.interpolate bilinear align_corners x3 + torch.cat). */
+int bpb_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, hipStream_t stream);
+int bpb_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, hipStream_t stream);
+int bpb_maxpool3x3s2_fwd(const float* x, float* y, unsigned char* idx, int N, int H, int W, int C, hipStream_t stream);
+int bpb_maxpool3x3s2_bwd(const float* dy, const unsigned char* idx, float* dx, int N, int H, int W, int C, int accumulate,
+                         hipStream_t stream);
+int bpb_bilinear_concat_fwd(const BpbBilinearArgs* a, hipStream_t stream);
+int bpb_bilinear_concat_bwd(const BpbBilinearArgs* a, float* dsrc, hipStream_t stream);
+
+/* ---- body-part attention head -----------------------------------------------------------------------------------
+ * torchreid/models/bpbreid.py:147-148 (PixelToPartClassifier :376-385 + softmax), :157-158,178 (bg/parts/fg masks),
+ * :182-192 (visibility scores), :195 (global average pool), :198-202 with :458-468 (GAP heads) and :490-503 (GWAP head). */
+int bpb_pixel_dots(const float* x, const float* w, long w_image_stride, const float* bias, float* out, int N, int HW, int C,
+                   int J, hipStream_t stream);
+int bpb_masked_pool(const float* x, const float* m, float* part, int N, int HW, int C, int J, int* nchunks_out,
+                    hipStream_t stream);
+int bpb_fold_bn(const float* w, const float* b, const float* scale, const float* shift, float* wf, float* bf, int K1, int C,
+                hipStream_t stream);
+int bpb_softmax_masks(const float* logits, float* scores, float* probs, float* pm, unsigned char* argpart,
+                      unsigned char* argcls, int N, int HW, int K1, hipStream_t stream);
+int bpb_visibility(const float* probs, const unsigned char* argcls, float* vis, float* fgvis, int N, int HW, int K1,
+                   int binary, hipStream_t stream);
+int bpb_pool_finalize(const float* part, const float* pm, float* pooled, float* zinv, int N, int nchunks, int J, int HW,
+                      int C, hipStream_t stream);
+int bpb_rowdot(const float* a, const float* b, float* out, int rows, int C, hipStream_t stream);
+int bpb_head_bwd_dlogits(const float* D, const float* probs, const unsigned char* argpart, const float* zinv,
+                         const float* gp, const float* dlogit_ext, float* dlogit, int N, int HW, int K1, hipStream_t stream);
+int bpb_head_bwd_params(const float* part, int nparts, const float* dlogit, int N, int HW, int K1, int C, const float* W,
+                        const float* gamma, const float* beta, const float* mean, const float* invstd, float* dW,
+                        float* dbias, float* dgamma, float* dbeta, float* k1, float* k2, int accumulate, hipStream_t stream);
+int bpb_head_bwd_dx(const float* x, const float* G, const float* pm, const float* zinv, const float* dlogit, const float* W,
+                    const float* gamma, const float* mean, const float* invstd, const float* k1, const float* k2, float* dx,
+                    int N, int HW, int C, int K1, int accumulate, hipStream_t stream);
+
+/* ---- dense layers after pooling ------------------------------------------------------------------------------------
+ * bpbreid.py:324-350 (AfterPoolingDimReduceLayer: Linear + BatchNorm1d + ReLU), :398-415 (BNClassifier), :261-279. */
+int bpb_gemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc, const float* bias,
+             int M, int N, int K, int accumulate, float* ws, int* nsplit_out, hipStream_t stream);
+int bpb_colsum(const float* X, float* out, int M, int N, int accumulate, hipStream_t stream);
+int bpb_bn1d_fwd(const float* x, long ldx, float* y, long ldy, int R, int F, const float* gamma, const float* beta,
+                 float* running_mean, float* running_var, float* save_mean, float* save_invstd, float eps, float momentum,
+                 int training, int relu, hipStream_t stream);
+int bpb_bn1d_bwd(const float* dy, long lddy, const float* x, long ldx, const float* y, long ldy, float* dx, long lddx, int R,
+                 int F, const float* gamma, const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
+                 int relu, int accumulate_params, hipStream_t stream);
+
+/* ---- GiLt objective -------------------------------------------------------------------------------------------------
+ * torchreid/losses/cross_entropy_loss.py:34-56; torchreid/losses/body_part_attention_loss.py:45-52 with
+ * engine/image/part_based_engine.py:114-128; torchreid/losses/part_averaged_triplet_loss.py:35-224 and the
+ * part_{max,min,max_min,individual}_triplet_loss.py variants; torchreid/utils/tensortools.py:3-21. */
+int bpb_ce_label_smooth(const float* logits, long ld, const long* targets, int target_div, const float* w,
+                        int acc_on_selected, int R, int C, float eps, float* row_loss, float* row_ok, float* dlogits,
+                        long ldd, float* out, hipStream_t stream);
+int bpb_pixel_ce(const float* scores, const float* masks, int N, int K1, int H, int W, int Hm, int Wm, float eps,
+                 float* dscores, double* partial, int nblocks, float* out, hipStream_t stream);
+int bpb_part_triplet(const float* emb, long se_n, long se_k, const long* pids, const float* vis, int vis_is_bool,
+                     const unsigned char* drop, int N, int K, int D, int strategy, float margin, float epsilon, float* dist,
+                     float* pair, int* pair_part, float* gsq, float* out, hipStream_t stream);
+int bpb_part_triplet_bwd(const float* emb, long se_n, long se_k, const float* gsq, const float* gscale, float gmul, int N,
+                         int K, int D, float* demb, long sd_n, long sd_k, int accumulate, hipStream_t stream);
+int bpb_scale(const float* x, const float* alpha_dev, float alpha, float* y, long n, int accumulate, hipStream_t stream);
+
+/* ---- optimizer step: torchreid/optim/optimizer.py:113-119 (torch.optim.Adam, coupled weight decay) ------------------ */
+int bpb_adam_step(float* p, const float* g, float* m, float* v, const long* blk_off, const int* blk_len, int nblocks,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int step_index, float gscale,
+                  hipStream_t stream);
+int bpb_fill(float* x, float value, long n, hipStream_t stream);
+
+/* ---- eval: torchreid/metrics/distance.py:87-247 and torchreid/metrics/rank.py:97-159 (rank_cylib/rank_cy.pyx:154-241) */
+int bpb_part_distance(const float* qf, const float* gf, const float* qvis, const float* gvis, int Q, int G, int P, int D,
+                      int mode, int strat, int cosine, float* qsq, float* gsq, int* maxbits, float* parts_out,
+                      float* dist_out, int finalize, hipStream_t stream);
+int bpb_part_distance_fill(float* x, long n, const int* maxbits, hipStream_t stream);
+int bpb_eval_rank(const float* distmat, const int64_t* q_pids, const int64_t* g_pids, const int64_t* q_camids,
+                  const int64_t* g_camids, int Q, int G, int max_rank, int nthreads, float* cmc_out, double* map_out,
+                  int* num_valid_out, int32_t* indices_out);
+
+/* ---- launch-plan executor: the static op list of one forward / backward (hrnet.py:532-576, resnet.py:342-358) ------ */
+int bpb_plan_run(const BpbPlanOp* ops, int nops, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BPBREID_HIP_H */

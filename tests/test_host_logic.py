@@ -1,0 +1,155 @@
+"""CPU tests of the host side: library loads and exports the C-ABI, descriptor geometry (via the NumPy
+emulator of the conv kernels' index algebra), native rank evaluator, optimizer tables, distributed reducer."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from bpbreid_amd import native as nv
+from bpbreid_amd import graph
+from bpbreid_amd.graph import Net, Act, choose_tile
+import conv_emulator as emu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = nv.lib()
+    header = open(os.path.join(ROOT, 'include', 'bpbreid_hip.h')).read()
+    declared = set(re.findall(r'\b(bpb_[a-z0-9_]+)\s*\(', header))
+    assert declared, 'header declares nothing?'
+    for name in declared:
+        assert hasattr(lib, name), 'libbpbreid_hip.so does not export %s' % name
+    assert set(nv.EXPORTS) <= declared | {'bpb_last_error'}
+    assert lib.bpb_last_error() is not None
+
+
+def test_struct_layouts_match_the_c_side():
+    # sizes are asserted against values printed by the compiler (static_asserts live in csrc/abi_check.cpp)
+    assert C.sizeof(nv.ConvProb) == 5 * 8 + 38 * 4 + 2 * 4
+    assert C.sizeof(nv.WgradProb) == 3 * 8 + 26 * 4 + 2 * 4
+    assert C.sizeof(nv.PlanOp) == 4 + 11 * 4 + 4 * 4 + 2 * 8 + 12 * 8
+
+
+def test_choose_tile_minimises_padding():
+    assert choose_tile(64, 64, 32, 256) == (1, 8, 32)
+    assert choose_tile(64, 8, 4, 256) == (8, 8, 4)
+    ti, th, tw = choose_tile(4, 24, 8, 256)
+    assert ti * th * tw == 256 and tw == 8
+    ti, th, tw = choose_tile(2, 2, 1, 256)
+    assert ti * th * tw == 256
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad
+    (2, 8, 6, 8, 16, 3, 1, 1),
+    (3, 9, 5, 16, 8, 3, 2, 1),
+    (2, 6, 4, 8, 40, 1, 1, 0),
+    (2, 7, 5, 8, 8, 1, 2, 0),
+    (1, 12, 10, 3, 8, 7, 2, 3),
+    (2, 10, 6, 3, 8, 3, 2, 1),
+    (5, 2, 1, 8, 8, 3, 1, 1),
+    (1, 20, 34, 8, 8, 3, 1, 1),
+    (2, 8, 8, 48, 96, 3, 2, 1),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_descriptors_forward_dgrad_wgrad(case):
+    n, h, w, cin, cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    wt = torch.randn(cout, cin, k, k, generator=g, dtype=torch.float64)
+    wt_param = wt.float().clone()
+    wt_param.grad = torch.zeros_like(wt_param)
+    xin = torch.randn(n, cin, h, w, generator=g, dtype=torch.float64)
+    net = Net(torch.device('cpu'))
+    cpad = 4 if cin == 3 else cin
+    x = Act(net, n, h, w, cpad)
+    x.needs_grad = cin != 3
+    node = net.conv(x, wt_param, stride, pad, bn=None)
+    net.nodes.append(('fuse', (Act(net, node.y.N, node.y.H, node.y.W, node.y.C), [(node.y, 0)], False)))
+    net.finalize(train_backward=True)
+    # ---- forward
+    x_nhwc = np.zeros((n, h, w, cpad))
+    x_nhwc[..., :cin] = xin.permute(0, 2, 3, 1).numpy()
+    prob = net.debug_convs[0][0]
+    y = np.zeros((n, node.y.H, node.y.W, cout))
+    stats = emu.run_conv(prob, x_nhwc, emu.pack_fwd(wt.numpy(), cpad), y)
+    ref = F.conv2d(xin, wt, stride=stride, padding=pad).permute(0, 2, 3, 1).numpy()
+    assert np.allclose(y, ref, atol=1e-9), 'forward geometry'
+    assert np.allclose(stats[:, 0].sum(0), ref.sum((0, 1, 2)), atol=1e-8)
+    # ---- data gradient (parity classes, accumulate flags)
+    gy = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    xr = xin.clone().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    F.conv2d(xr, wr, stride=stride, padding=pad).backward(gy.permute(0, 3, 1, 2))
+    if x.needs_grad:
+        gx = np.full((n, h, w, cin), np.nan)
+        dprobs = [d[0] for d in net.debug_convs[1:]]
+        assert len(dprobs) >= 1
+        first = True
+        for dp in dprobs:
+            assert dp.accumulate == 0      # single consumer in this mini graph
+            if first:
+                gx[:] = 0 if stride == 1 else gx
+                first = False
+            emu.run_conv(dp, gy.numpy(), emu.pack_dgrad(wt.numpy(), cpad), gx)
+        assert not np.isnan(gx).any(), 'dgrad classes do not cover every input pixel'
+        assert np.allclose(gx, xr.grad.permute(0, 2, 3, 1).numpy(), atol=1e-9), 'dgrad geometry'
+    # ---- weight gradient
+    wp = net.debug_wgrads[0][0]
+    dw = emu.run_wgrad(wp, x_nhwc, gy.numpy())                           # [T][Cin_pad][Cout]
+    ref_dw = wr.grad.permute(2, 3, 1, 0).reshape(k * k, cin, cout).numpy()
+    assert np.allclose(dw[:, :cin], ref_dw, atol=1e-8), 'wgrad geometry'
+
+
+def test_rank_native_matches_golden(golden_dir):
+    from bpbreid_amd.metrics import evaluate_rank
+    z = np.load(os.path.join(golden_dir, 'metrics.npz'))
+    res = evaluate_rank(z['rank/distmat'], z['rank/q_pids'], z['rank/g_pids'], z['rank/q_cam'], z['rank/g_cam'],
+                        return_indices=True, nthreads=3)
+    assert np.array_equal(res['indices'], z['rank/indices'])            # bit-exact ranking on tie-free rows
+    assert np.allclose(res['cmc'], z['rank/cmc'], atol=1e-7)
+    assert abs(res['mAP'] - float(z['rank/mAP'])) < 1e-12
+    res2 = evaluate_rank(z['rank/distmat'], z['rank2/q_pids'], z['rank/g_pids'], z['rank/q_cam'], z['rank/g_cam'])
+    assert np.allclose(res2['cmc'], z['rank2/cmc'], atol=1e-7) and abs(res2['mAP'] - float(z['rank2/mAP'])) < 1e-12
+
+
+def test_rank_native_ties_are_stable_and_errors_are_loud():
+    from bpbreid_amd.metrics import evaluate_rank
+    dm = np.zeros((2, 6), dtype=np.float32)                              # all ties: order must be the gallery index
+    res = evaluate_rank(dm, [1, 2], [1, 2, 1, 2, 3, 3], [0, 0], [1, 1, 1, 1, 1, 1], max_rank=6, return_indices=True)
+    assert np.array_equal(res['indices'], np.tile(np.arange(6), (2, 1)))
+    assert np.array_equal(np.argsort(dm, axis=1, kind='stable'), res['indices'])
+    with pytest.raises(AssertionError):
+        evaluate_rank(dm, [7, 8], [1, 2, 1, 2, 3, 3], [0, 0], [1] * 6)
+    with pytest.raises(ValueError):
+        evaluate_rank(dm, [1, 2], [1, 2, 1, 2, 3, 3], [0, 0], [1] * 6, eval_metric='cuhk03')
+
+
+def test_model_refuses_to_run_without_gpu():
+    import common as Cm
+    from bpbreid_amd.model import bpbreid
+    model = bpbreid(4, config=Cm.make_cfg('hrnet_w8', 2, 16), pretrained=False)
+    keys = set(model.state_dict().keys())
+    assert 'backbone_appearance_feature_extractor.stage4.2.fuse_layers.3.0.2.0.weight' in keys
+    assert 'parts_identity_classifier.1.classifier.weight' in keys
+    with pytest.raises(nv.NativeError):
+        model(torch.zeros(2, 3, 64, 32))
+
+
+@pytest.mark.parametrize('name', ['hrnet_w8', 'hrnet32', 'hrnet48', 'resnet50'])
+def test_state_dict_keys_equal_the_oracle(name):
+    """The oracle's keys are pinned to the reference by test_oracle_vs_golden (fill-by-key would diverge otherwise)."""
+    import common as Cm
+    from bpbreid_amd.model import bpbreid
+    from oracle.bpbreid import BPBreID as OracleModel
+    cfg = Cm.make_cfg(name, 5, 64)
+    a = bpbreid(7, config=cfg, pretrained=False).state_dict()
+    b = OracleModel(7, cfg).state_dict()
+    assert list(a.keys()) == list(b.keys())
+    assert all(a[k].shape == b[k].shape for k in a)
