@@ -1,0 +1,177 @@
+"""Headline benchmark: images/sec of the BPBReID train step (HRNet-W32, K=5 parts, 256x128, batch 64 per GPU).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one pass of the hot path over one synthetic batch already resident in HBM: backbone forward, part-attention
+pooling head, GiLt (identity CE + part triplet) + pixel CE, backward, gradient all-reduce (N > 1, RCCL), fused Adam.
+Rank 0 prints ONE JSON line; `roofline` is measured live with HIP events on the launch stream (bpb_plan_run_timed),
+`cpu_baseline` times the CPU oracle (a port of the reference's algorithm) on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'tests', 'golden')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch                                                   # noqa: E402
+import torch.distributed as dist                               # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+WEIGHTS = {'globl': {'id': 1., 'tr': 0.}, 'foreg': {'id': 1., 'tr': 0.}, 'conct': {'id': 1., 'tr': 0.},
+           'parts': {'id': 0., 'tr': 1.}, 'pixls': {'ce': 0.35}}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--backbone', default='hrnet32')
+    ap.add_argument('--batch', type=int, default=64, help='per-GPU batch')
+    ap.add_argument('--parts', type=int, default=5)
+    ap.add_argument('--height', type=int, default=256)
+    ap.add_argument('--width', type=int, default=128)
+    ap.add_argument('--classes', type=int, default=751)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=16)
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """The CPU oracle (a restatement of the reference's PyTorch path, materialised mask x feature product included)
+    timed on the host cores: bounded sample = batch `cpu_batch`, 1 warm-up + 2 timed steps (fwd + loss + bwd + Adam)."""
+    import common as Cm
+    from oracle.bpbreid import BPBreID as OracleModel
+    from oracle import losses as OL
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = Cm.make_cfg(args.backbone, args.parts, 512)
+    model = Cm.fill_state_dict_(OracleModel(args.classes, cfg)).train()
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=3.5e-4, weight_decay=5e-4)
+    n = args.cpu_batch
+    imgs, masks, pids = Cm.synth_batch(n, args.height, args.width, args.parts, args.classes)
+    times = []
+    for it in range(3):
+        t0 = time.perf_counter()
+        out = model(imgs, masks)
+        loss, _ = OL.combined_loss(out, pids, masks)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    t = sum(times[1:]) / 2
+    return {'value': n / t, 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '%s K=%d %dx%d, batch %d (GPU batch is %d), 1 warm-up + 2 timed train steps, fp32, oracle/ port of the '
+                      'reference PyTorch-CPU path' % (args.backbone, args.parts, args.height, args.width, n, args.batch)}
+
+
+def roofline(model, plan):
+    """Live per-launch durations (HIP events on the launch stream) of one forward + backward of the backbone plan.
+    Dominant kernel = the kernel symbol with the largest summed duration; achieved = its algorithmic FLOPs / its time."""
+    net = plan.net
+    rows = net.run_timed(net.plan_train) + net.run_timed(net.plan_bwd)
+    agg = {}
+    for meta, ms in rows:
+        lab = meta['label']
+        sym = lab.split(' ', 1)[1] if ' ' in lab else lab
+        a = agg.setdefault(sym, {'ms': 0.0, 'flops': 0.0, 'bytes': 0.0, 'launches': 0})
+        a['ms'] += ms
+        a['flops'] += meta['flops']
+        a['bytes'] += meta['bytes']
+        a['launches'] += 1
+    total_ms = sum(a['ms'] for a in agg.values())
+    sym, dom = max(agg.items(), key=lambda kv: kv[1]['ms'])
+    conv_flops = sum(a['flops'] for a in agg.values())
+    conv_ms = sum(a['ms'] for a in agg.values() if a['flops'] > 0)
+    if dom['flops'] > 0:
+        achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+        r = {'bound': 'mfma', 'kernel': sym, 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+             'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None}
+    else:
+        achieved = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
+        r = {'bound': 'hbm', 'kernel': sym, 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
+             'traffic': None}
+    r.update({'avg_launch_us': dom['ms'] * 1e3 / dom['launches'], 'launches_per_step': dom['launches'],
+              'kernel_ms_per_step': dom['ms'], 'backbone_ms_fwd_bwd': total_ms,
+              'all_conv_tflops': conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else None,
+              'all_conv_frac_of_f32_mfma_peak': conv_flops / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS if conv_ms else None,
+              'by_kernel_ms': {k: round(v['ms'], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])[:12]}})
+    return r
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+    import common as Cm
+    from bpbreid_amd.model import bpbreid
+    from bpbreid_amd.engine import ImagePartBasedEngine
+    from bpbreid_amd.optim import FusedAdam
+    from bpbreid_amd.distributed import broadcast_parameters
+    cfg = Cm.make_cfg(args.backbone, args.parts, 512)
+    model = Cm.fill_state_dict_(bpbreid(args.classes, config=cfg, pretrained=False)).to(dev)
+    arena = model.arena()
+    if world > 1:
+        broadcast_parameters([arena['param'], arena['fbuf']])
+    eng = ImagePartBasedEngine(model, optimizer=FusedAdam(model, lr=3.5e-4, weight_decay=5e-4), losses_weights=WEIGHTS,
+                               mask_filtering_training=True, distributed=world > 1)
+    imgs, masks, pids = Cm.synth_batch(args.batch, args.height, args.width, args.parts, args.classes, seed=1234 + rank)
+    data = {'image': imgs.to(dev), 'mask': masks.to(dev), 'pid': pids.to(dev)}      # resident in HBM before timing
+    for _ in range(args.warmup):
+        loss, _ = eng.forward_backward(data)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = eng.forward_backward(data)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    final_loss = float(loss)
+    result = {
+        'metric': 'images/sec (train step, HRNet-W32 K=5 parts, 256x128) at 1/2/4/8 GPUs', 'value': world * args.batch * args.steps / elapsed,
+        'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': '%s K=%d parts, %dx%d, batch %d per GPU (global %d), GiLt part-triplet + ID loss + pixel CE with '
+                               'visibility masks, fwd+loss+bwd+all-reduce+Adam (BASELINE configs[2]/[3])'
+                               % (args.backbone, args.parts, args.height, args.width, args.batch, args.batch * world),
+                   'parallelism': 'dp%d' % world, 'global_batch': args.batch * world, 'final_loss': final_loss},
+    }
+    if rank == 0 and world == 1 and not args.no_roofline:
+        plan = next(iter(model._plans.values()))
+        result['roofline'] = roofline(model, plan)
+        step_flops = 3.0 * sum(m['flops'] for m in plan.net.plan_train[2])
+        result['roofline']['step_conv_tflops'] = step_flops / (elapsed / args.steps) / 1e12
+        result['roofline']['step_frac_of_f32_mfma_peak'] = result['roofline']['step_conv_tflops'] / PEAK_F32_MFMA_TFLOPS
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result['cpu_baseline'] = cpu_baseline(args)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -276,7 +276,8 @@ __global__ __launch_bounds__(256) void bpb_conv_wgrad_kernel(const BpbWgradProb*
     // M-tile range of this split
     const int per = (P.n_mtiles + P.nsplit - 1) / P.nsplit;
     const int mt_begin = split * per, mt_end = min(P.n_mtiles, mt_begin + per);
-    const int vpp = 8;   // float4 per halo pixel (32 channels; channels >= ckc are zero-filled)
+    const int vpp = ckc >> 2;   // float4 per halo pixel.  When ckc < 32 the A fragment of lanes >= ckc reads past the row
+                                // (other pixels / the dy tile): those MFMA rows are never stored, rows are independent.
 
     for (int mtile = mt_begin; mtile < mt_end; ++mtile) {
         const int tb = mtile % P.tiles_b, t2 = mtile / P.tiles_b;
@@ -284,15 +285,15 @@ __global__ __launch_bounds__(256) void bpb_conv_wgrad_kernel(const BpbWgradProb*
         const int n0 = tn << lTI, a0 = ta << lTH, b0 = tb << lTW;
         __syncthreads();
         for (int idx = threadIdx.x; idx < npix_h * vpp; idx += 256) {
-            const int v = idx & 7;
-            const unsigned hp = (unsigned)idx >> 3;
+            const unsigned hp = (unsigned)idx / (unsigned)vpp;
+            const int v = idx - hp * vpp;
             const unsigned t = bpb_fdiv(hp, HWd, P.magic_hw);
             const int hc = hp - t * HWd;
             const unsigned ti = bpb_fdiv(t, HH, P.magic_hh);
             const int hr = t - ti * HH;
             const int n = n0 + (int)ti, ih = a0 * sa + hr + P.ih0, iw = b0 * sa + hc + P.iw0;
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (v * 4 < ckc && n < P.N && (unsigned)ih < (unsigned)P.Hi && (unsigned)iw < (unsigned)P.Wi)
+            if (n < P.N && (unsigned)ih < (unsigned)P.Hi && (unsigned)iw < (unsigned)P.Wi)
                 val = BPB_GLD4((bpb_gcf)P.x + (((size_t)n * P.Hi + ih) * P.Wi + iw) * Cin + ci0 + v * 4);
             *(f32x4*)(sx + hp * LD + v * 4) = val;
         }
@@ -489,7 +490,7 @@ int bpb_conv_wgrad(const BpbWgradProb* d_probs, const BpbWgradProb* h_probs, int
         const BpbWgradProb& p = h_probs[i];
         BPB_REQUIRE(p.Cin % 4 == 0 && p.Cout % 4 == 0, "bpb_conv_wgrad: Cin/Cout must be multiples of 4");
         BPB_REQUIRE(p.lTI + p.lTH + p.lTW == 7, "bpb_conv_wgrad: M tile must be 128 pixels");
-        BPB_REQUIRE(p.LD >= 32 && p.LD % 4 == 0, "bpb_conv_wgrad: bad LDS pitch");
+        BPB_REQUIRE(p.LD % 4 == 0 && p.LD >= (p.Cin < 32 ? p.Cin : 32), "bpb_conv_wgrad: bad LDS pitch");
         BPB_REQUIRE(p.T >= 1 && p.S >= 1 && p.T % p.S == 0, "bpb_conv_wgrad: T=%d S=%d", p.T, p.S);
         BPB_REQUIRE(p.blk_begin == nblk, "bpb_conv_wgrad: blk_begin mismatch");
         const int this_ntw = (p.T == 1 && p.Cout >= 128) ? 4 : (p.T == 1 && p.Cout >= 64) ? 2 : 1;

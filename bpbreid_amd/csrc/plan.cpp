@@ -4,12 +4,45 @@
 // per-launch argument marshalling.  This is the native counterpart of the reference's module-by-module
 // Python dispatch (torchreid/models/hrnet.py:532-576 runs ~650 nn.Module calls per forward).
 // The same array can be recorded into a hipGraph by capturing the stream around bpb_plan_run.
+#include <vector>
+
 #include "bpb_common.h"
+
+static int run_one(const BpbPlanOp& o, int k, hipStream_t stream);
 
 extern "C" int bpb_plan_run(const BpbPlanOp* ops, int nops, hipStream_t stream)
 {
     for (int k = 0; k < nops; ++k) {
-        const BpbPlanOp& o = ops[k];
+        const int rc = run_one(ops[k], k, stream);
+        if (rc != 0) return rc;
+    }
+    return 0;
+}
+
+// Measurement variant: brackets every op with HIP events ON THE SAME STREAM and returns the elapsed
+// milliseconds per op in ms_out[nops] (synchronises at the end).  Used by bench.py for the live per-kernel
+// durations behind the roofline numbers; never used on the training path.
+extern "C" int bpb_plan_run_timed(const BpbPlanOp* ops, int nops, hipStream_t stream, float* ms_out)
+{
+    std::vector<hipEvent_t> ev(nops + 1);
+    for (auto& e : ev)
+        if (hipEventCreate(&e) != hipSuccess) return bpb_set_error(1, "bpb_plan_run_timed: hipEventCreate failed");
+    (void)hipEventRecord(ev[0], stream);
+    int rc = 0;
+    for (int k = 0; k < nops && rc == 0; ++k) {
+        rc = run_one(ops[k], k, stream);
+        (void)hipEventRecord(ev[k + 1], stream);
+    }
+    (void)hipStreamSynchronize(stream);
+    if (rc == 0)
+        for (int k = 0; k < nops; ++k) (void)hipEventElapsedTime(&ms_out[k], ev[k], ev[k + 1]);
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
+static int run_one(const BpbPlanOp& o, int k, hipStream_t stream)
+{
+    {
         int rc = 0;
         switch (o.kind) {
             case BPB_OP_CONV:   // p0 device probs, p1 host probs, i0 nprobs
@@ -70,7 +103,6 @@ extern "C" int bpb_plan_run(const BpbPlanOp* ops, int nops, hipStream_t stream)
             default:
                 return bpb_set_error(-1, "bpb_plan_run: unknown op kind %d at index %d", o.kind, k);
         }
-        if (rc != 0) return rc;
+        return rc;
     }
-    return 0;
 }

@@ -50,6 +50,18 @@ def choose_tile(n, a, b, pixels):
     return best[1], best[2], best[3]
 
 
+class PlanList(list):
+    """Launch records plus, for measurement, one metadata dict per record (label, algorithmic flops / bytes)."""
+
+    def __init__(self):
+        super().__init__()
+        self.meta = []
+
+    def add(self, op, label, flops=0.0, bytes_=0.0):
+        self.append(op)
+        self.meta.append({'label': label, 'flops': float(flops), 'bytes': float(bytes_)})
+
+
 class Act:
     """An NHWC activation (and, after backward planning, its gradient) resident in HBM."""
 
@@ -95,7 +107,7 @@ class Net:
         self.nodes = []            # (kind, payload) in forward order
         self.keep = []             # ctypes objects / tensors that must outlive the plans
         self.convs = []
-        self.fwd_train, self.fwd_eval, self.bwd = [], [], []
+        self.fwd_train, self.fwd_eval, self.bwd = PlanList(), PlanList(), PlanList()
         self.debug_convs = []      # (ConvProb, x, packed w, y) -- lets the CPU tests emulate the descriptors
         self.debug_wgrads = []     # (WgradProb, ConvNode)
 
@@ -222,11 +234,16 @@ class Net:
         self.debug_convs.append((p, x_buf, w_packed, y_buf))
         return p
 
-    def _emit_conv(self, plans, prob):
+    def _emit_conv(self, plans, prob, label):
         dev = self._dev_struct(prob)
         op = self._op(nv.OP_CONV, ints=(1,), ptrs=(dev, C.addressof(prob)))
+        nt = 1 if prob.Cout <= 32 else 2
+        variant = 'bpb_conv_igemm_kernel<%d,%s>' % (nt, 'true' if prob.Cin == 4 else 'false')
+        npix = prob.N * prob.A * prob.B
+        flops = 2.0 * npix * prob.Rt * prob.St * prob.Cin * prob.Cout
+        bytes_ = 4.0 * (prob.N * prob.Hi * prob.Wi * prob.Cin + npix * prob.Cout)
         for pl in plans:
-            pl.append(op)
+            pl.add(op, '%s %s' % (label, variant), flops, bytes_)
 
     # ------------------------------------------------------------------ freeze
     def finalize(self, train_backward=True):
@@ -249,8 +266,8 @@ class Net:
             blk += -(-(t * cin_pad * cout) // 256)
         dpacks = self._dev_struct(packs)
         pack_op = self._op(nv.OP_PACK, ints=(len(self.convs), blk), ptrs=(dpacks,))
-        self.fwd_train.append(pack_op)
-        self.fwd_eval.append(pack_op)
+        self.fwd_train.add(pack_op, 'pack_weights')
+        self.fwd_eval.add(pack_op, 'pack_weights')
         both = (self.fwd_train, self.fwd_eval)
 
         # ---- forward
@@ -259,7 +276,7 @@ class Net:
                 n, c, h, w = self.in_shape
                 op = self._op(nv.OP_NCHW_TO_NHWC4, ints=(n, c, h, w), ptrs=(self.in_buf, pay.buf))
                 for pl in both:
-                    pl.append(op)
+                    pl.add(op, 'nchw_to_nhwc4', 0, 4.0 * n * h * w * 7)
             elif kind == 'conv':
                 cv = pay
                 x, y = cv.x, cv.y
@@ -267,18 +284,18 @@ class Net:
                 prob = self.conv_problem(x.buf, (x.N, x.H, x.W), cv.wf, y.buf, (y.H, y.W), y.H, y.W, (1, 1, 0, 0),
                                          cv.stride, (-cv.pad, -cv.pad), (cv.R, cv.S, 0, 1, 0, 1, 0, cv.S, 1), x.C, y.C,
                                          bias=cv.bias, stats=stats)
-                self._emit_conv(both, prob)
+                self._emit_conv(both, prob, 'conv_fwd')
                 if cv.bn is not None:
                     bn = cv.bn
                     cv.stats_buf = stats[0]
                     count = float(y.N * y.H * y.W)
-                    self.fwd_train.append(self._op(
+                    self.fwd_train.add(self._op(
                         nv.OP_BN_FINALIZE, ints=(prob.n_mtiles, y.C), floats=(BN_EPS, BN_MOMENTUM), doubles=(count,),
                         ptrs=(cv.stats_buf, bn.weight, bn.bias, bn.scale, bn.shift, bn.mean, bn.invstd, bn.running_mean,
-                              bn.running_var)))
-                    self.fwd_eval.append(self._op(
+                              bn.running_var)), 'bn_finalize')
+                    self.fwd_eval.add(self._op(
                         nv.OP_BN_EVAL_AFFINE, ints=(y.C,), floats=(BN_EPS,),
-                        ptrs=(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.scale, bn.shift)))
+                        ptrs=(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.scale, bn.shift)), 'bn_eval_affine')
             elif kind == 'fuse':
                 out, terms, relu = pay
                 fa = FuseArgs()
@@ -300,13 +317,15 @@ class Net:
                 assert out.N * out.H * out.W * max(out.H, out.W) < (1 << 32)
                 self.keep.append(fa)
                 op = self._op(nv.OP_FUSE_FWD, ptrs=(C.addressof(fa),))
+                elems = out.N * out.H * out.W * out.C
+                rd = sum((t.y if isinstance(t, ConvNode) else t).buf.numel() for t, _ in terms)
                 for pl in both:
-                    pl.append(op)
+                    pl.add(op, 'fuse_fwd', 0, 4.0 * (elems + rd))
             elif kind == 'maxpool':
                 x, y, idx = pay
                 op = self._op(nv.OP_MAXPOOL_FWD, ints=(x.N, x.H, x.W, x.C), ptrs=(x.buf, y.buf, idx))
                 for pl in both:
-                    pl.append(op)
+                    pl.add(op, 'maxpool_fwd', 0, 4.0 * (x.buf.numel() + 1.25 * y.buf.numel()))
             elif kind == 'concat':
                 out, srcs = pay
                 c0 = 0
@@ -314,7 +333,7 @@ class Net:
                     ba = self._bilinear_args(a.buf, out.buf, a, out, c0)
                     op = self._op(nv.OP_BILINEAR_FWD, ptrs=(C.addressof(ba),))
                     for pl in both:
-                        pl.append(op)
+                        pl.add(op, 'bilinear_concat_fwd', 0, 4.0 * (a.buf.numel() + a.N * out.H * out.W * a.C))
                     c0 += a.C
         if train_backward:
             self._emit_backward()
@@ -340,7 +359,7 @@ class Net:
         for k, op in enumerate(ops):
             arr[k] = op
         self.keep.append(arr)
-        return arr, len(ops)
+        return arr, len(ops), list(ops.meta)
 
     # ------------------------------------------------------------------ backward plan
     def _emit_backward(self):
@@ -358,7 +377,8 @@ class Net:
                 for a, off in zip(srcs, offs):
                     a.ensure_grad(self)
                     ba = self._bilinear_args(a.buf, out.ensure_grad(self), a, out, off, accumulate=a.take_acc_flag())
-                    bwd.append(self._op(nv.OP_BILINEAR_BWD, ptrs=(C.addressof(ba), a.grad)))
+                    bwd.add(self._op(nv.OP_BILINEAR_BWD, ptrs=(C.addressof(ba), a.grad)), 'bilinear_concat_bwd', 0,
+                            4.0 * (a.buf.numel() + 4 * a.N * out.H * out.W * a.C))
             elif kind == 'fuse':
                 out, terms, relu = pay
                 gout = out.ensure_grad(self)
@@ -383,22 +403,28 @@ class Net:
                         ta.dsrc = a.ensure_grad(self).data_ptr()
                         ta.partials = part.data_ptr()
                         ta.accumulate = a.take_acc_flag()
-                        bwd.append(self._op(nv.OP_TERM_BWD, ints=(1, nblocks), ptrs=(C.addressof(ta),)))
-                        bwd.append(self._op(nv.OP_BN_BWD_FINALIZE, ints=(nblocks, a.C, 0), doubles=(float(npix),),
-                                            ptrs=(part, bn.weight.grad, bn.bias.grad, bn.c1, bn.c2)))
-                        bwd.append(self._op(nv.OP_TERM_BWD, ints=(2, 0), ptrs=(C.addressof(ta),)))
+                        win = 4 ** up
+                        eb = 4.0 * a.buf.numel()
+                        bwd.add(self._op(nv.OP_TERM_BWD, ints=(1, nblocks), ptrs=(C.addressof(ta),)), 'bn_bwd_reduce', 0,
+                                eb * (1 + 2 * win))
+                        bwd.add(self._op(nv.OP_BN_BWD_FINALIZE, ints=(nblocks, a.C, 0), doubles=(float(npix),),
+                                         ptrs=(part, bn.weight.grad, bn.bias.grad, bn.c1, bn.c2)), 'bn_bwd_finalize')
+                        bwd.add(self._op(nv.OP_TERM_BWD, ints=(2, 0), ptrs=(C.addressof(ta),)), 'bn_bwd_apply', 0,
+                                eb * (2 + 2 * win))
                     else:
                         if not a.needs_grad:
                             continue
                         ta.dsrc = a.ensure_grad(self).data_ptr()
                         ta.accumulate = a.take_acc_flag()
-                        bwd.append(self._op(nv.OP_TERM_BWD, ints=(0, 0), ptrs=(C.addressof(ta),)))
+                        bwd.add(self._op(nv.OP_TERM_BWD, ints=(0, 0), ptrs=(C.addressof(ta),)), 'identity_bwd', 0,
+                                4.0 * a.buf.numel() * (1 + 2 * 4 ** up))
             elif kind == 'maxpool':
                 x, y, idx = pay
                 if x.needs_grad:
                     x.ensure_grad(self)
-                    bwd.append(self._op(nv.OP_MAXPOOL_BWD, ints=(x.N, x.H, x.W, x.C, x.take_acc_flag()),
-                                        ptrs=(y.ensure_grad(self), idx, x.grad)))
+                    bwd.add(self._op(nv.OP_MAXPOOL_BWD, ints=(x.N, x.H, x.W, x.C, x.take_acc_flag()),
+                                     ptrs=(y.ensure_grad(self), idx, x.grad)), 'maxpool_bwd', 0,
+                            4.0 * (x.buf.numel() + 1.25 * y.buf.numel()))
             elif kind == 'conv':
                 self._emit_conv_backward(pay, ws_requests)
         # one split-K slab workspace shared by every weight-gradient launch (they run back to back on one stream)
@@ -432,7 +458,7 @@ class Net:
         wp.lTI, wp.lTH, wp.lTW = _log2(ti), _log2(th), _log2(tw)
         wp.HH = (th - 1) * cv.stride + r
         wp.HW = (tw - 1) * cv.stride + s
-        wp.LD = 36
+        wp.LD = 36 if x.C >= 32 else x.C + 4
         wp.tiles_a, wp.tiles_b = -(-y.H // th), -(-y.W // tw)
         wp.n_mtiles = (-(-x.N // ti)) * wp.tiles_a * wp.tiles_b
         ntw = 4 if (t == 1 and cout >= 128) else 2 if (t == 1 and cout >= 64) else 1
@@ -450,11 +476,13 @@ class Net:
         dev = self._dev_struct(wp)
         self._wgrad_descs.append((dev, wp))
         self.debug_wgrads.append((wp, cv))
-        bwd.append(self._op(nv.OP_WGRAD, ints=(1,), ptrs=(dev, C.addressof(wp))))
+        tg = 1 if t == 1 else 9
+        bwd.add(self._op(nv.OP_WGRAD, ints=(1,), ptrs=(dev, C.addressof(wp))), 'conv_wgrad bpb_conv_wgrad_kernel<%d,%d>' % (tg, ntw),
+                2.0 * y.N * y.H * y.W * t * x.C * cout, 4.0 * (x.buf.numel() + y.buf.numel()))
         # the shared workspace pointer is patched into both records once its size is known (end of _emit_backward)
         red = self._op(nv.OP_WGRAD_REDUCE, ints=(wp.nsplit, t, x.C, cin_real, cout, 0), ptrs=(None, cv.weight.grad))
         self._pending_reduce.append((red, wp))
-        bwd.append(red)
+        bwd.add(red, 'wgrad_reduce', 0, 4.0 * (elems + t * cin_real * cout))
         if cv.bias is not None:
             raise NotImplementedError('conv bias gradient on the backbone path')
         # ---- data gradient
@@ -481,9 +509,16 @@ class Net:
                 taps = (rt, stt, max(rt - 1, 0), -1, max(stt - 1, 0), -1, rf * s + sf, st * s, st)
                 prob = self.conv_problem(gy, (y.N, y.H, y.W), cv.wd, gx, (x.H, x.W), a, b, (st, st, ph, pw), 1,
                                          (ih0, iw0), taps, cout, x.C, accumulate=acc)
-                self._emit_conv([bwd], prob)
+                self._emit_conv([bwd], prob, 'conv_dgrad')
 
     # ------------------------------------------------------------------ execution
     def run(self, plan):
-        arr, n = plan
+        arr, n = plan[0], plan[1]
         nv.call('bpb_plan_run', C.cast(arr, C.c_void_p), n, nv.stream())
+
+    def run_timed(self, plan):
+        """Measurement only: returns [(meta, milliseconds)] for every launch record of the plan."""
+        arr, n, meta = plan
+        ms = (C.c_float * max(1, n))()
+        nv.call('bpb_plan_run_timed', C.cast(arr, C.c_void_p), n, nv.stream(), C.cast(ms, C.c_void_p))
+        return [(meta[k], ms[k]) for k in range(n)]

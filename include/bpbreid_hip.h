@@ -265,6 +265,8 @@ int bpb_eval_rank(const float* distmat, const int64_t* q_pids, const int64_t* g_
 
 /* ---- launch-plan executor: the static op list of one forward / backward (hrnet.py:532-576, resnet.py:342-358) ------ */
 int bpb_plan_run(const BpbPlanOp* ops, int nops, hipStream_t stream);
+/* measurement only: per-op elapsed milliseconds via HIP events on `stream` (synchronises) */
+int bpb_plan_run_timed(const BpbPlanOp* ops, int nops, hipStream_t stream, float* ms_out);
 
 #ifdef __cplusplus
 }

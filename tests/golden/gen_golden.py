@@ -98,10 +98,10 @@ MODEL_CASES = {
                           {'training_binary_visibility_score': False, 'testing_binary_visibility_score': False}),
     'hrw8_k3_shared': ('hrnet_w8', 3, 64, 8, 64, 32, 16, {'shared_parts_id_classifier': True}),
     'hr32_k5': ('hrnet32', 5, 512, 8, 128, 64, 16, {}),
-    'hr32_k5_full': ('hrnet32', 5, 512, 4, 256, 128, 751, {}),
+    'hr32_k5_full': ('hrnet32', 5, 512, 8, 256, 128, 751, {}),
     'r50_k2': ('resnet50', 2, 512, 8, 128, 64, 16, {}),
     'r50_k5_full': ('resnet50', 5, 512, 8, 256, 128, 751, {}),
-    'hr48_k8': ('hrnet48', 8, 512, 4, 192, 64, 16, {}),
+    'hr48_k8': ('hrnet48', 8, 512, 8, 192, 64, 16, {}),
 }
 
 

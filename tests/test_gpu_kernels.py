@@ -1,0 +1,438 @@
+"""GPU parity tests, kernel level: every HIP kernel family against an fp64 PyTorch-CPU evaluation of the same math
+(and against the oracle for the losses / metrics).  All calls go through the C-ABI.  Run with `-m gpu` on an MI355X.
+
+Tolerances: the kernels are exact fp32 (MFMA f32 == fma chain), so errors are fp32 round-off of K-long sums:
+|err| <= 2e-5 * scale is asserted for convolutions (K up to 2304), 1e-5 for elementwise work."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import common as Cm                                         # noqa: E402
+from bpbreid_amd import native as nv                        # noqa: E402
+from bpbreid_amd.graph import Net, Act                      # noqa: E402
+from bpbreid_amd import backbones as PB                     # noqa: E402
+from oracle import backbones as OB                          # noqa: E402
+from oracle import losses as OL                             # noqa: E402
+from oracle import metrics as OM                            # noqa: E402
+
+DEV = torch.device('cuda', 0)
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _init():
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    nv.init_device()
+    loaded = [l for l in open('/proc/self/maps').read().splitlines() if 'libbpbreid_hip.so' in l]
+    assert loaded, 'native library not mapped'
+
+
+def rel_err(got, ref):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def test_mfma_f32_layout_via_identity_conv():
+    """A = I check with an asymmetric B (guide rule 16): 1x1 conv with identity weights must copy, with a
+    permutation matrix must permute channels, nothing transposed."""
+    n, h, w, c = 2, 16, 16, 32
+    x = torch.randn(n, c, h, w)
+    perm = torch.randperm(c)
+    wt = torch.zeros(c, c, 1, 1)
+    wt[torch.arange(c), perm, 0, 0] = 1.0                     # y[:, o] = x[:, perm[o]]
+    net = Net(DEV)
+    xa = Act(net, n, h, w, c)
+    xa.buf.copy_(nhwc(x))
+    wp = wt.to(DEV)
+    wp.grad = torch.zeros_like(wp)
+    node = net.conv(xa, wp, 1, 0)
+    net.finalize(train_backward=False)
+    net.run(net.plan_train)
+    torch.cuda.synchronize()
+    assert torch.equal(nchw(node.y.buf.cpu()), x[:, perm])
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad
+    (4, 64, 32, 32, 32, 3, 1, 1),
+    (4, 32, 16, 64, 64, 3, 1, 1),
+    (6, 16, 8, 128, 128, 3, 1, 1),
+    (16, 8, 4, 256, 256, 3, 1, 1),
+    (4, 64, 32, 3, 64, 3, 2, 1),
+    (2, 64, 32, 3, 64, 7, 2, 3),
+    (4, 32, 16, 64, 64, 3, 2, 1),
+    (3, 33, 17, 32, 128, 3, 2, 1),
+    (4, 64, 32, 64, 256, 1, 1, 0),
+    (4, 16, 8, 1024, 2048, 1, 2, 0),
+    (4, 16, 8, 512, 2048, 1, 1, 0),
+    (2, 24, 8, 48, 96, 3, 2, 1),
+    (2, 24, 8, 96, 48, 1, 1, 0),
+    (5, 2, 1, 8, 8, 3, 1, 1),
+    (3, 5, 3, 16, 40, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_forward_backward(case):
+    n, h, w, cin, cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(1000 + sum(case))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    net = Net(DEV)
+    cpad = 4 if cin == 3 else cin
+    xa = Act(net, n, h, w, cpad)
+    xa.needs_grad = cin != 3
+    xin = torch.zeros(n, h, w, cpad)
+    xin[..., :cin] = nhwc(x)
+    xa.buf.copy_(xin)
+    wp = wt.to(DEV)
+    wp.grad = torch.zeros_like(wp)
+    gamma, beta = torch.ones(cout, device=DEV), torch.zeros(cout, device=DEV)
+    gamma.grad, beta.grad = torch.zeros_like(gamma), torch.zeros_like(beta)
+    rm, rv = torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV)
+    node = net.conv(xa, wp, stride, pad, bn=(gamma, beta, rm, rv))
+    out = net.fuse([(node, 0)], relu=False)
+    net.finalize(train_backward=True)
+    net.run(net.plan_train)
+    torch.cuda.synchronize()
+    xr = x.double().requires_grad_(True)
+    wr = wt.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, stride=stride, padding=pad)
+    assert rel_err(nchw(node.y.buf), yr.detach()) < 2e-5, 'conv forward'
+    # BatchNorm batch statistics from the conv epilogue partials
+    bn_ref = F.batch_norm(yr, None, None, training=True, eps=1e-5)
+    assert rel_err(nchw(out.buf), bn_ref.detach()) < 5e-5, 'bn apply'
+    m = n * yr.shape[2] * yr.shape[3]
+    assert rel_err(rm, 0.1 * yr.detach().mean((0, 2, 3))) < 1e-4
+    assert rel_err(rv - 0.9, 0.1 * yr.detach().var((0, 2, 3), unbiased=True) * (1 if m > 1 else 0)) < 1e-4
+    # backward through BN + conv
+    gr = torch.randn(out.buf.shape, generator=g)
+    out.grad.copy_(gr)
+    net.run(net.plan_bwd)
+    torch.cuda.synchronize()
+    gb = torch.ones(cout, dtype=torch.float64, requires_grad=True)
+    bb = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    o2 = F.batch_norm(yr, None, None, gb, bb, training=True, eps=1e-5)
+    o2.backward(nchw(gr).double())
+    assert rel_err(wp.grad, wr.grad) < 1e-4, 'wgrad'
+    assert rel_err(gamma.grad, gb.grad) < 1e-4 and rel_err(beta.grad, bb.grad) < 1e-4, 'bn param grads'
+    if xa.needs_grad:
+        assert rel_err(nchw(xa.grad), xr.grad) < 1e-4, 'dgrad'
+
+
+def _module_parity(pmod, omod, in_shapes, train_steps=1):
+    """Emit a product module into a plan, run fwd/bwd on the GPU, compare with the oracle module in fp64 on the CPU."""
+    Cm.fill_state_dict_(omod)
+    pmod.load_state_dict(omod.state_dict())
+    omod = omod.double().train()
+    pmod = pmod.to(DEV)
+    for p in pmod.parameters():
+        p.grad = torch.zeros_like(p)
+    g = torch.Generator().manual_seed(7)
+    xs = [torch.randn(*s, generator=g) for s in in_shapes]
+    net = Net(DEV)
+    acts = []
+    for x in xs:
+        a = Act(net, x.shape[0], x.shape[2], x.shape[3], x.shape[1])
+        a.buf.copy_(nhwc(x))
+        acts.append(a)
+    outs = pmod.emit(net, acts if len(acts) > 1 else acts[0])
+    outs = outs if isinstance(outs, (list, tuple)) else [outs]
+    net.finalize(train_backward=True)
+    net.run(net.plan_train)
+    xr = [x.double().requires_grad_(True) for x in xs]
+    refs = omod(xr if len(xr) > 1 else xr[0])
+    refs = refs if isinstance(refs, (list, tuple)) else [refs]
+    torch.cuda.synchronize()
+    for o, r in zip(outs, refs):
+        assert rel_err(nchw(o.buf), r.detach()) < 1e-4, 'module forward'
+    loss = 0
+    for o, r in zip(outs, refs):
+        gr = torch.randn(r.shape, generator=g)
+        o.grad.copy_(nhwc(gr))
+        loss = loss + (r * gr.double()).sum()
+    loss.backward()
+    net.run(net.plan_bwd)
+    torch.cuda.synchronize()
+    for a, x in zip(acts, xr):
+        assert rel_err(nchw(a.grad), x.grad) < 3e-4, 'input grad'
+    ref_params = dict(omod.named_parameters())
+    worst = 0.0
+    for name, p in pmod.named_parameters():
+        if ref_params[name].grad is None:
+            continue
+        worst = max(worst, rel_err(p.grad, ref_params[name].grad))
+    assert worst < 5e-4, 'param grads %g' % worst
+    sd_ref = omod.state_dict()
+    for name, b in pmod.named_buffers():
+        if b.dtype == torch.float32:
+            assert rel_err(b, sd_ref[name]) < 1e-4, name
+
+
+def test_basic_block():
+    _module_parity(PB.Residual(32, 32, False), OB.Residual(32, 32, False), [(4, 32, 16, 8)])
+
+
+def test_bottleneck_with_strided_downsample():
+    _module_parity(PB.Residual(64, 32, True, 2), OB.Residual(64, 32, True, 2), [(3, 64, 16, 8)])
+
+
+def test_multires_module_three_branches():
+    _module_parity(PB.MultiResModule([8, 16, 32]), OB.MultiResModule([8, 16, 32]),
+                   [(2, 8, 16, 8), (2, 16, 8, 4), (2, 32, 4, 2)])
+
+
+class _OracleStem(nn.Module):
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+
+    def forward(self, x):
+        return self.net(x)
+
+
+def test_full_backbones_forward_backward():
+    for name, shape in (('hrnet_w8', (2, 3, 64, 32)), ('resnet50', (2, 3, 64, 32))):
+        pm = PB.build_backbone(name, 5)
+        om = OB.build_backbone(name, 5)
+        Cm.fill_state_dict_(om)
+        pm.load_state_dict(om.state_dict())
+        om = om.double().train()
+        pm = pm.to(DEV)
+        for p in pm.parameters():
+            p.grad = torch.zeros_like(p)
+        g = torch.Generator().manual_seed(11)
+        x = torch.randn(*shape, generator=g)
+        net = Net(DEV)
+        xa = net.input_nchw(*shape)
+        out = pm.emit(net, xa)
+        net.finalize(train_backward=True)
+        net.in_buf.copy_(x)
+        net.run(net.plan_train)
+        ref = om(x.double())
+        torch.cuda.synchronize()
+        assert rel_err(nchw(out.buf), ref.detach()) < 2e-4, name
+        gr = torch.randn(ref.shape, generator=g)
+        out.grad.copy_(nhwc(gr))
+        (ref * gr.double()).sum().backward()
+        net.run(net.plan_bwd)
+        torch.cuda.synchronize()
+        rp = dict(om.named_parameters())
+        worst = max(rel_err(p.grad, rp[n].grad) for n, p in pm.named_parameters() if rp[n].grad is not None)
+        assert worst < 2e-3, (name, worst)
+        # eval-mode plan (running statistics)
+        om.eval()
+        net.run(net.plan_eval)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            ref_e = om(x.double())
+        assert rel_err(nchw(out.buf), ref_e) < 2e-4, name + ' eval'
+
+
+def test_maxpool_and_bilinear_concat():
+    g = torch.Generator().manual_seed(5)
+    net = Net(DEV)
+    x = torch.randn(3, 16, 13, 9, generator=g)
+    xa = Act(net, 3, 13, 9, 16)
+    xa.buf.copy_(nhwc(x))
+    y = net.maxpool(xa)
+    a2 = Act(net, 3, 4, 3, 8)
+    x2 = torch.randn(3, 8, 4, 3, generator=g)
+    a2.buf.copy_(nhwc(x2))
+    a3 = Act(net, 3, 2, 1, 12)
+    x3 = torch.randn(3, 12, 2, 1, generator=g)
+    a3.buf.copy_(nhwc(x3))
+    cat = net.concat_bilinear([y, a2, a3])
+    net.finalize(train_backward=True)
+    net.run(net.plan_train)
+    torch.cuda.synchronize()
+    xr, x2r, x3r = [t.double().requires_grad_(True) for t in (x, x2, x3)]
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    size = yr.shape[2:]
+    ref = torch.cat([yr, F.interpolate(x2r, size=size, mode='bilinear', align_corners=True),
+                     F.interpolate(x3r, size=size, mode='bilinear', align_corners=True)], 1)
+    assert rel_err(nchw(cat.buf), ref.detach()) < 1e-6
+    gr = torch.randn(ref.shape, generator=g)
+    cat.grad.copy_(nhwc(gr))
+    (ref * gr.double()).sum().backward()
+    net.run(net.plan_bwd)
+    torch.cuda.synchronize()
+    assert rel_err(nchw(xa.grad), xr.grad) < 1e-6
+    assert rel_err(nchw(a2.grad), x2r.grad) < 1e-5
+    assert rel_err(nchw(a3.grad), x3r.grad) < 1e-5
+
+
+def test_triplet_family_against_golden_and_oracle(golden_dir):
+    from bpbreid_amd.losses import init_part_based_triplet_loss
+    z = np.load(os.path.join(golden_dir, 'losses.npz'))
+    emb = torch.from_numpy(z['emb'])
+    vis = {'none': None, 'bool': torch.from_numpy(z['vis_bool']), 'float': torch.from_numpy(z['vis_float'])}
+    keys = [k for k in z.files if k.startswith('tri/') and k.endswith('/vals') and 'random' not in k]
+    assert len(keys) >= 40
+    for key in keys:
+        _, name, vname, pname, m, _ = key.split('/')
+        e = emb.clone().to(DEV).requires_grad_(True)
+        v = vis[vname].to(DEV) if vis[vname] is not None else None
+        lossf = init_part_based_triplet_loss(name, margin=float(m[1:]))
+        res = lossf(e, torch.from_numpy(z[pname]).to(DEV), parts_visibility=v)
+        got = np.array([float(x) for x in res])
+        assert np.allclose(got, z[key], rtol=2e-5, atol=2e-6), (key, got, z[key])
+        res[0].backward()
+        assert np.allclose(e.grad.cpu().numpy(), z[key[:-5] + '/grad'], rtol=2e-4, atol=2e-6), key
+
+
+def test_ce_and_gilt_against_golden(golden_dir):
+    from bpbreid_amd.losses import CrossEntropyLoss, GiLtLoss
+    z = np.load(os.path.join(golden_dir, 'losses.npz'))
+    logits, tgt, w = [torch.from_numpy(z['ce/' + k]).to(DEV) for k in ('logits', 'targets', 'weights')]
+    for nm, ww in (('plain', None), ('weighted', w)):
+        lg = logits.clone().requires_grad_(True)
+        v = CrossEntropyLoss()(lg, tgt, ww)
+        v.backward()
+        assert abs(float(v) - float(z['ce/%s/val' % nm])) < 2e-6
+        assert np.allclose(lg.grad.cpu().numpy(), z['ce/%s/grad' % nm], atol=1e-7)
+    n, k = z['emb'].shape[:2]
+    ncls = z['ce/logits'].shape[1]
+    pids = (torch.from_numpy(z['pids']) % ncls).to(DEV)
+    wts = {'globl': {'id': 1., 'tr': 0.5}, 'foreg': {'id': 1., 'tr': 1.}, 'conct': {'id': 1., 'tr': 0.},
+           'parts': {'id': 0.7, 'tr': 1.}}
+    for vname in ('none', 'bool', 'float'):
+        pv = torch.from_numpy(z['vis_float'] if vname == 'float' else z['vis_bool']).to(DEV)
+        one = torch.ones(n, device=DEV) if vname == 'float' else torch.ones(n, dtype=torch.bool, device=DEV)
+        visd = {'globl': one, 'foreg': pv.amax(1), 'conct': pv.amax(1), 'parts': pv}
+        emb = {kk: torch.from_numpy(z['gilt/emb/' + kk]).to(DEV).requires_grad_(True) for kk in wts}
+        ids = {kk: torch.from_numpy(z['gilt/ids/' + kk]).to(DEV).requires_grad_(True) for kk in wts}
+        loss, summ = GiLtLoss(wts, use_visibility_scores=(vname != 'none'))(emb, visd, ids, pids)
+        assert abs(float(loss) - float(z['gilt/%s/loss' % vname])) < 5e-5, vname
+        loss.backward()
+        for kk in wts:
+            for nm, t in (('gemb', emb[kk]), ('gids', ids[kk])):
+                key = 'gilt/%s/%s/%s' % (vname, nm, kk)
+                if key in z.files:
+                    assert np.allclose(t.grad.cpu().numpy(), z[key], rtol=2e-4, atol=2e-6), key
+        for kk, info in summ.items():
+            for nm, v in info.items():
+                assert abs(float(v) - float(z['gilt/%s/summ/%s/%s' % (vname, kk, nm)])) < 5e-5, (vname, kk, nm)
+
+
+def test_pixel_ce_against_oracle():
+    from bpbreid_amd.losses import BodyPartAttentionLoss
+    g = torch.Generator().manual_seed(3)
+    scores = torch.randn(3, 6, 16, 8, generator=g)
+    for hm, wm in ((16, 8), (64, 32), (7, 5)):
+        masks = torch.softmax(15 * torch.rand(3, 6, hm, wm, generator=g), 1)
+        sr = scores.clone().requires_grad_(True)
+        ref, acc = OL.body_part_attention(sr, masks)
+        ref.backward()
+        sg = scores.to(DEV).requires_grad_(True)
+        loss, summ = BodyPartAttentionLoss()(sg, masks.to(DEV))
+        loss.backward()
+        assert abs(float(loss) - float(ref)) < 2e-6
+        assert abs(float(summ['pixls']['a']) - float(acc)) < 1e-6
+        assert np.allclose(sg.grad.cpu().numpy(), sr.grad.numpy(), atol=1e-8)
+
+
+def test_part_distance_against_golden(golden_dir):
+    from bpbreid_amd.metrics import compute_distance_matrix_using_bp_features
+    z = np.load(os.path.join(golden_dir, 'metrics.npz'))
+    qf, gf = torch.from_numpy(z['qf']), torch.from_numpy(z['gf'])
+    vis = {'none': (None, None), 'bool': (torch.from_numpy(z['qv']), torch.from_numpy(z['gv'])),
+           'float': (torch.from_numpy(z['qvf']), torch.from_numpy(z['gvf']))}
+    for key in [k for k in z.files if k.startswith('dist/') and k.endswith('/b5000/distmat')]:
+        _, vname, strat, metric, b, _ = key.split('/')
+        dm, pm = compute_distance_matrix_using_bp_features(qf, gf, vis[vname][0], vis[vname][1], strat, 500, True, metric)
+        assert np.allclose(dm.numpy(), z[key], atol=3e-6), key
+        assert np.allclose(pm.numpy(), z[key[:-8] + '/parts'], atol=3e-6), key
+
+
+def test_part_distance_large_ranking_identical_to_oracle():
+    """Config-5 shaped check at reduced size: Q=256, G=3000, P=9, D=512 -> identical rankings (ties as sets)."""
+    from bpbreid_amd.metrics import compute_distance_matrix_using_bp_features, evaluate_rank
+    g = torch.Generator().manual_seed(4321)
+    q, G, p, d = 256, 3000, 9, 512
+    qf = F.normalize(torch.randn(q, p, d, generator=g), dim=-1)
+    gf = F.normalize(torch.randn(G, p, d, generator=g), dim=-1)
+    qv = torch.rand(q, p, generator=g) < 0.8
+    gv = torch.rand(G, p, generator=g) < 0.8
+    qv[:, 0] = True
+    gv[:, 0] = True
+    dm, pm = compute_distance_matrix_using_bp_features(qf, gf, qv, gv, 'mean', 500, True, 'euclidean')
+    dm_ref, pm_ref = OM.part_based_distance(qf, gf, qv, gv, 'mean', 500, 'euclidean')
+    assert (dm - dm_ref).abs().max() < 5e-6 and (pm - pm_ref).abs().max() < 5e-6
+    ia = np.argsort(dm.numpy(), axis=1, kind='stable')
+    ib = np.argsort(dm_ref.numpy(), axis=1, kind='stable')
+    # a swap is only legitimate between gallery entries whose reference distances differ by less than fp32 round-off
+    diff = ia != ib
+    if diff.any():
+        rows, cols = np.nonzero(diff)
+        da = np.take_along_axis(dm_ref.numpy(), ia, 1)[rows, cols]
+        db = np.take_along_axis(dm_ref.numpy(), ib, 1)[rows, cols]
+        assert np.abs(da - db).max() < 1e-5
+    pids_q = torch.randint(0, 300, (q,), generator=g).numpy()
+    pids_g = torch.randint(0, 300, (G,), generator=g).numpy()
+    cq = torch.randint(0, 6, (q,), generator=g).numpy()
+    cg = torch.randint(0, 6, (G,), generator=g).numpy()
+    a = evaluate_rank(dm.numpy(), pids_q, pids_g, cq, cg)
+    b = OM.evaluate_rank(dm_ref.numpy(), pids_q, pids_g, cq, cg)
+    assert np.allclose(a['cmc'], b['cmc'], atol=1e-6) and abs(a['mAP'] - b['mAP']) < 1e-6
+
+
+def test_fused_adam_matches_torch():
+    from bpbreid_amd.optim import FusedAdam
+
+    class Tiny(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = nn.Parameter(torch.randn(1000))
+            self.b = nn.Parameter(torch.randn(37, 5))
+            self.c = nn.Parameter(torch.randn(9))           # never receives a gradient
+            self._arena, self._param_slices = None, None
+
+        def arena(self):
+            if self._arena is None:
+                params = list(self.parameters())
+                sizes = [(p.numel() + 3) // 4 * 4 for p in params]
+                flat = torch.zeros(sum(sizes), device=DEV)
+                grad = torch.zeros(sum(sizes), device=DEV)
+                off, self._param_slices = 0, []
+                for p, s in zip(params, sizes):
+                    v = flat[off:off + p.numel()].view(p.shape)
+                    v.copy_(p.data)
+                    p.data = v
+                    p.grad = grad[off:off + p.numel()].view(p.shape)
+                    self._param_slices.append((off, p.numel()))
+                    off += s
+                self._arena = dict(param=flat, grad=grad, params=params)
+            return self._arena
+
+    torch.manual_seed(0)
+    m = Tiny()
+    ref = [p.detach().clone().double().requires_grad_(True) for p in m.parameters()]
+    topt = torch.optim.Adam(ref[:2], lr=3.5e-4, weight_decay=5e-4)
+    m.arena()
+    m.c.grad = None
+    opt = FusedAdam(m)
+    for step in range(3):
+        for p, r in zip(list(m.parameters())[:2], ref[:2]):
+            gnew = torch.randn(p.shape)
+            p.grad.copy_(gnew)
+            r.grad = gnew.double()
+        opt.step()
+        topt.step()
+    torch.cuda.synchronize()
+    for p, r in zip(m.parameters(), ref):
+        assert rel_err(p.data, r.data) < 1e-6

@@ -1,0 +1,158 @@
+"""GPU parity tests, model level: the full BPBreID hot path on the MI355X against the golden vectors produced by the
+real reference (tests/golden/*.npz, fp32 target + fp64 arbiter) -- forward (train + eval), GiLt + pixel loss,
+parameter gradients, BatchNorm running statistics, and a 2-step Adam trajectory (BASELINE config 1).
+
+Tolerance model: |gpu - ref64| <= max(c * |ref32 - ref64|, 2e-4 * scale): the fp32 GPU result may
+differ from the fp32 CPU reference by summation order, but must be as close to the fp64 arbiter as the reference is."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import common as Cm                                            # noqa: E402
+from bpbreid_amd.model import bpbreid                         # noqa: E402
+from bpbreid_amd.engine import ImagePartBasedEngine           # noqa: E402
+from bpbreid_amd.optim import FusedAdam                       # noqa: E402
+
+DEV = torch.device('cuda', 0)
+
+MODEL_CASES = {
+    'hrw8_k5': ('hrnet_w8', {}),
+    'hrw8_k5_float_vis': ('hrnet_w8', {'training_binary_visibility_score': False, 'testing_binary_visibility_score': False}),
+    'hrw8_k3_shared': ('hrnet_w8', {'shared_parts_id_classifier': True}),
+    'hr32_k5': ('hrnet32', {}),
+    'r50_k2': ('resnet50', {}),
+    'hr48_k8': ('hrnet48', {}),
+    'hr32_k5_full': ('hrnet32', {}),
+    'r50_k5_full': ('resnet50', {}),
+}
+WEIGHTS_MARKET = {'globl': {'id': 1., 'tr': 0.}, 'foreg': {'id': 1., 'tr': 1.}, 'conct': {'id': 1., 'tr': 0.},
+                  'parts': {'id': 0., 'tr': 1.}, 'pixls': {'ce': 0.35}}
+WEIGHTS_DEFAULT = {'globl': {'id': 1., 'tr': 0.}, 'foreg': {'id': 1., 'tr': 0.}, 'conct': {'id': 1., 'tr': 0.},
+                   'parts': {'id': 0., 'tr': 1.}, 'pixls': {'ce': 0.35}}
+
+
+def close(got, ref32, ref64, c=8.0, rel=2e-4, what=''):
+    got, ref32, ref64 = [np.asarray(a, dtype=np.float64) for a in (got, ref32, ref64)]
+    scale = max(np.abs(ref64).max(), 1e-12)
+    noise = np.abs(ref32 - ref64).max()
+    err = np.abs(got - ref64).max()
+    assert err <= max(c * noise, rel * scale), (what, err, noise, scale)
+
+
+def check_outputs(z, tag32, tag64, out):
+    emb, vis, ids, pix, sp, mk = out
+    for k, v in emb.items():
+        close(Cm.to_np(v), z['%s/emb/%s' % (tag32, k)], z['%s/emb/%s' % (tag64, k)], what='emb ' + k)
+    for k, v in ids.items():
+        close(Cm.to_np(v), z['%s/ids/%s' % (tag32, k)], z['%s/ids/%s' % (tag64, k)], what='ids ' + k)
+    for k, v in vis.items():
+        ref = z['%s/vis/%s' % (tag32, k)]
+        if ref.dtype == np.bool_:
+            assert v.dtype is torch.bool and np.array_equal(Cm.to_np(v), ref), 'visibility ' + k
+        else:
+            close(Cm.to_np(v), ref, z['%s/vis/%s' % (tag64, k)], what='vis ' + k)
+    close(Cm.to_np(pix), z[tag32 + '/pix'], z[tag64 + '/pix'], what='pix')
+    close(Cm.to_np(Cm.subsample(sp.contiguous())), z[tag32 + '/sp_sub'], z[tag64 + '/sp_sub'], what='spatial')
+    close(Cm.to_np(mk['parts']), z[tag32 + '/mask_parts'], z[tag64 + '/mask_parts'], what='masks')
+    close(Cm.to_np(mk['foreg']), z[tag32 + '/mask_foreg'], z[tag64 + '/mask_foreg'], what='fg mask')
+
+
+@pytest.mark.parametrize('name', list(MODEL_CASES))
+def test_model_matches_reference_golden(name, golden_dir):
+    path = os.path.join(golden_dir, 'model_%s.npz' % name)
+    if not os.path.exists(path):
+        pytest.skip('fixture not generated')
+    z = np.load(path)
+    backbone, extra = MODEL_CASES[name]
+    k, d, n, h, w, ncls = [int(x) for x in z['meta']]
+    cfg = Cm.make_cfg(backbone, k, d, **extra)
+    model = Cm.fill_state_dict_(bpbreid(ncls, config=cfg, pretrained=False)).to(DEV)
+    imgs, masks, pids = Cm.synth_batch(n, h, w, k, ncls)
+    imgs, masks, pids = imgs.to(DEV), masks.to(DEV), pids.to(DEV)
+    eng = ImagePartBasedEngine(model, optimizer=FusedAdam(model), losses_weights=WEIGHTS_MARKET, mask_filtering_training=True)
+    model.train()
+    out = model(imgs, external_parts_masks=masks)
+    check_outputs(z, 'f32/train', 'f64/train', out)
+    loss, summ = eng.combine_losses(out[1], out[0], out[2], pids, out[3], masks, bpa_weight=0.35)
+    close(float(loss.detach()), z['f32/loss_market_vis'], z['f64/loss_market_vis'], what='loss')
+    close(float(summ['pixls']['c'].detach()), z['f32/loss_bpa'], z['f64/loss_bpa'], what='bpa')
+    for kk, info in summ.items():
+        for nm, v in info.items():
+            if kk != 'pixls':
+                close(float(v), z['f32/summ/%s/%s' % (kk, nm)], z['f64/summ/%s/%s' % (kk, nm)], rel=1e-3, what='summary')
+    loss.backward()
+    torch.cuda.synchronize()
+    digests = Cm.grad_digest(model.named_parameters())
+    ref_names = [kk[len('f32/grad/'):] for kk in z.files if kk.startswith('f32/grad/')]
+    assert sorted(digests) == sorted(ref_names), 'set of parameters that receive a gradient differs'
+    bad = []
+    for pn, dg in digests.items():
+        r32, r64 = z['f32/grad/' + pn], z['f64/grad/' + pn]
+        scale = max(np.abs(r64[2:]).max(), np.abs(r64[1]) / max(1, r64.size), 1e-9)
+        noise = np.abs(r32[2:] - r64[2:]).max()
+        err = np.abs(dg[2:] - r64[2:]).max()
+        if err > max(10 * noise, 3e-3 * scale):
+            bad.append((pn, err, noise, scale))
+    assert not bad, bad[:5]
+    sd = model.state_dict()
+    rs = [kk for kk in sd if kk.endswith('running_mean') or kk.endswith('running_var')]
+    got = np.array([float(sd[kk].double().sum()) for kk in rs])
+    assert np.allclose(got, z['f64/running_digest'], rtol=2e-4, atol=2e-4)
+    assert int(sd['backbone_appearance_feature_extractor.bn1.num_batches_tracked']) == 1
+    model.eval()
+    with torch.no_grad():
+        out = model(imgs, external_parts_masks=masks)
+    check_outputs(z, 'f32/eval', 'f64/eval', out)
+
+
+def test_two_step_trajectory_config1(golden_dir):
+    """BASELINE config 1: ResNet-50, K=2, batch 16 of 256x128, default GiLt weights, Adam(3.5e-4, wd 5e-4): two steps."""
+    path = os.path.join(golden_dir, 'traj_r50_k2.npz')
+    if not os.path.exists(path):
+        pytest.skip('fixture not generated')
+    z = np.load(path)
+    k, d, n, h, w, ncls = 2, 512, 16, 256, 128, 751
+    model = Cm.fill_state_dict_(bpbreid(ncls, config=Cm.make_cfg('resnet50', k, d), pretrained=False)).to(DEV)
+    eng = ImagePartBasedEngine(model, optimizer=FusedAdam(model, lr=3.5e-4, weight_decay=5e-4), losses_weights=WEIGHTS_DEFAULT)
+    losses = []
+    for step in range(2):
+        imgs, masks, pids = Cm.synth_batch(n, h, w, k, ncls, seed=1234 + step)
+        loss, _ = eng.forward_backward({'image': imgs, 'mask': masks, 'pid': pids})
+        losses.append(float(loss))
+    assert np.allclose(losses, z['losses'], rtol=2e-4), (losses, z['losses'])
+    sd = model.state_dict()
+    got = Cm.to_np(Cm.subsample(sd['backbone_appearance_feature_extractor.conv1.weight'], 97))
+    assert np.allclose(got, z['conv1_w_sub'], atol=2e-5), np.abs(got - z['conv1_w_sub']).max()
+    got = Cm.to_np(sd['pixel_classifier.classifier.weight']).reshape(k + 1, -1)[:, ::64]
+    assert np.allclose(got, z['pixcls_w'], atol=2e-5)
+    # parameters without gradient (background branch, per-part classifiers, backbone fc) must not move at all
+    ref_model = Cm.fill_state_dict_(bpbreid(ncls, config=Cm.make_cfg('resnet50', k, d), pretrained=False))
+    for key in ('background_after_pooling_dim_reduce.layers.0.weight', 'parts_identity_classifier.0.classifier.weight',
+                'backbone_appearance_feature_extractor.classifier.weight'):
+        assert torch.equal(sd[key].cpu(), ref_model.state_dict()[key]), key
+
+
+def test_torch_optimizer_compat_path():
+    """The drop-in contract: loss.backward() + torch.optim.Adam(model.parameters()) works like with the reference."""
+    cfg = Cm.make_cfg('hrnet_w8', 3, 32)
+    model = Cm.fill_state_dict_(bpbreid(8, config=cfg, pretrained=False)).to(DEV)
+    model.train()
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+    from bpbreid_amd.losses import GiLtLoss
+    gilt = GiLtLoss()
+    imgs, masks, pids = Cm.synth_batch(8, 64, 32, 3, 8)
+    before = model.pixel_classifier.classifier.weight.detach().clone()
+    for _ in range(2):
+        emb, vis, ids, pix, sp, mk = model(imgs.to(DEV), external_parts_masks=masks.to(DEV))
+        loss, _ = gilt(emb, vis, ids, pids.to(DEV))
+        opt.zero_grad()
+        loss.backward()
+        assert model.background_after_pooling_dim_reduce.layers[0].weight.grad is None
+        assert model.global_after_pooling_dim_reduce.layers[0].weight.grad is not None
+        opt.step()
+    assert not torch.equal(before, model.pixel_classifier.classifier.weight.detach())
+    assert torch.isfinite(loss)
