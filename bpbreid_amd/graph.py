@@ -250,7 +250,7 @@ class Net:
         """Allocate packed weights / scratch and emit the three launch plans."""
         dev = self.device
         # ---- weight packing (one launch for the whole network)
-        packs = (PackProb * len(self.convs))()
+        packs = (PackProb * max(1, len(self.convs)))()
         blk = 0
         for k, cv in enumerate(self.convs):
             cout, cin_real, r, s = cv.weight.shape
@@ -264,10 +264,11 @@ class Net:
             pk.Cout, pk.Cin, pk.Cin_pad, pk.T = cout, cin_real, cin_pad, t
             pk.blk_begin = blk
             blk += -(-(t * cin_pad * cout) // 256)
-        dpacks = self._dev_struct(packs)
-        pack_op = self._op(nv.OP_PACK, ints=(len(self.convs), blk), ptrs=(dpacks,))
-        self.fwd_train.add(pack_op, 'pack_weights')
-        self.fwd_eval.add(pack_op, 'pack_weights')
+        if self.convs:
+            dpacks = self._dev_struct(packs)
+            pack_op = self._op(nv.OP_PACK, ints=(len(self.convs), blk), ptrs=(dpacks,))
+            self.fwd_train.add(pack_op, 'pack_weights')
+            self.fwd_eval.add(pack_op, 'pack_weights')
         both = (self.fwd_train, self.fwd_eval)
 
         # ---- forward

@@ -81,7 +81,7 @@ def grad_digest(named_params, nsample=8):
     for name, p in named_params:
         if p.grad is None:
             continue
-        gflat = p.grad.detach().flatten().double()
+        gflat = p.grad.detach().flatten().double().cpu()
         step = max(1, gflat.numel() // nsample)
         out[name] = torch.cat([gflat.sum()[None], gflat.abs().sum()[None], gflat[::step][:nsample]]).numpy()
     return out

@@ -305,25 +305,28 @@ def gen_traj():
     """Two full optimisation steps of config 1 (ResNet-50 K=2 N=16 256x128): loss trajectory."""
     from torchreid import models
     k, d, n, h, w, ncls = 2, 512, 16, 256, 128, 751
-    torch.manual_seed(0)
-    model = models.build_model('bpbreid', num_classes=ncls, loss='part_based', pretrained=False,
-                               config=ref_cfg('resnet50', k, d))
-    C.fill_state_dict_(model)
-    model.train()
-    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=3.5e-4,
-                           weight_decay=5e-4, betas=(0.9, 0.999))
     store = {}
-    losses = []
-    for step in range(2):
-        imgs, masks, pids = C.synth_batch(n, h, w, k, ncls, seed=1234 + step)
-        out = model(imgs, external_parts_masks=masks)
-        loss, _, _ = ref_combined_loss(out, pids, masks, WEIGHTS_DEFAULT, use_vis=False)
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-        losses.append(float(loss))
+    for dt, tag in ((torch.float64, 'losses64'), (torch.float32, 'losses')):
+        torch.manual_seed(0)
+        model = models.build_model('bpbreid', num_classes=ncls, loss='part_based', pretrained=False,
+                                   config=ref_cfg('resnet50', k, d))
+        C.fill_state_dict_(model)
+        model = model.to(dt).train()
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=3.5e-4,
+                               weight_decay=5e-4, betas=(0.9, 0.999))
+        losses = []
+        f32 = lambda dct: {kk: (v.float() if v.is_floating_point() else v) for kk, v in dct.items()}
+        for step in range(2):
+            imgs, masks, pids = C.synth_batch(n, h, w, k, ncls, seed=1234 + step)
+            out = model(imgs.to(dt), external_parts_masks=masks.to(dt))
+            out_l = (f32(out[0]), f32(out[1]), f32(out[2]), out[3].float(), out[4], out[5])
+            loss, _, _ = ref_combined_loss(out_l, pids, masks, WEIGHTS_DEFAULT, use_vis=False)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        store[tag] = np.array(losses)
     sd = model.state_dict()
-    store['losses'] = np.array(losses)
     store['conv1_w_sub'] = C.to_np(C.subsample(sd['backbone_appearance_feature_extractor.conv1.weight'], 97))
     store['pixcls_w'] = C.to_np(sd['pixel_classifier.classifier.weight']).reshape(k + 1, -1)[:, ::64]
     store['gid_cls_sub'] = C.to_np(C.subsample(sd['global_identity_classifier.classifier.weight'], 997))

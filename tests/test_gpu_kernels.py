@@ -206,11 +206,13 @@ class _OracleStem(nn.Module):
 
 
 def test_full_backbones_forward_backward():
-    for name, shape in (('hrnet_w8', (2, 3, 64, 32)), ('resnet50', (2, 3, 64, 32))):
+    import copy
+    for name, shape in (('hrnet_w8', (8, 3, 64, 32)), ('resnet50', (4, 3, 64, 32))):
         pm = PB.build_backbone(name, 5)
         om = OB.build_backbone(name, 5)
         Cm.fill_state_dict_(om)
         pm.load_state_dict(om.state_dict())
+        om32 = copy.deepcopy(om).train()
         om = om.double().train()
         pm = pm.to(DEV)
         for p in pm.parameters():
@@ -224,16 +226,27 @@ def test_full_backbones_forward_backward():
         net.in_buf.copy_(x)
         net.run(net.plan_train)
         ref = om(x.double())
+        with torch.no_grad():
+            noise = rel_err(om32(x), ref.detach())           # the fp32 CPU path's own distance to the fp64 arbiter
         torch.cuda.synchronize()
-        assert rel_err(nchw(out.buf), ref.detach()) < 2e-4, name
+        err = rel_err(nchw(out.buf), ref.detach())
+        assert err < max(8 * noise, 2e-4), (name, err, noise)
         gr = torch.randn(ref.shape, generator=g)
         out.grad.copy_(nhwc(gr))
         (ref * gr.double()).sum().backward()
         net.run(net.plan_bwd)
         torch.cuda.synchronize()
         rp = dict(om.named_parameters())
-        worst = max(rel_err(p.grad, rp[n].grad) for n, p in pm.named_parameters() if rp[n].grad is not None)
-        assert worst < 2e-3, (name, worst)
+        (om32(x) * gr).sum().backward()
+        rp32 = dict(om32.named_parameters())
+        bad = []
+        for n, p in pm.named_parameters():
+            if rp[n].grad is None:
+                continue
+            e, nz = rel_err(p.grad, rp[n].grad), rel_err(rp32[n].grad, rp[n].grad)
+            if e > max(10 * nz, 2e-3):
+                bad.append((n, e, nz))
+        assert not bad, (name, bad[:4])
         # eval-mode plan (running statistics)
         om.eval()
         net.run(net.plan_eval)
