@@ -41,7 +41,43 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=16)
+    ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     return ap.parse_args()
+
+
+def host_cores():
+    """Cores this process may really use: CPU affinity, capped by the cgroup CPU quota (os.cpu_count() reports the whole
+    host inside a container and oversubscribing OpenMP threads by 10x makes a CPU step arbitrarily slow)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline_subprocess(args, timeout=240):
+    """Run the CPU baseline in a child with a hard timeout so that the benchmark always terminates."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', '--backbone', args.backbone, '--parts', str(args.parts),
+           '--height', str(args.height), '--width', str(args.width), '--classes', str(args.classes), '--cpu-batch', str(args.cpu_batch),
+           '--batch', str(args.batch)]
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env['CUDA_VISIBLE_DEVICES'] = ''
+    env['HIP_VISIBLE_DEVICES'] = ''
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout, env=env)
+        for line in r.stdout.decode().splitlines()[::-1]:
+            if line.startswith('{'):
+                return json.loads(line)
+        return {'value': None, 'unit': 'images/sec', 'cores': host_cores(), 'kind': 'port', 'sample': 'cpu baseline produced no result'}
+    except subprocess.TimeoutExpired:
+        return {'value': None, 'unit': 'images/sec', 'cores': host_cores(), 'kind': 'port',
+                'sample': 'cpu baseline exceeded its %d s budget (batch %d)' % (timeout, args.cpu_batch)}
 
 
 def cpu_baseline(args):
@@ -50,7 +86,7 @@ def cpu_baseline(args):
     import common as Cm
     from oracle.bpbreid import BPBreID as OracleModel
     from oracle import losses as OL
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     cfg = Cm.make_cfg(args.backbone, args.parts, 512)
     model = Cm.fill_state_dict_(OracleModel(args.classes, cfg)).train()
@@ -108,6 +144,9 @@ def roofline(model, plan):
 
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args)))
+        return
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -149,7 +188,7 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
     result = {
         'metric': 'images/sec (train step, HRNet-W32 K=5 parts, 256x128) at 1/2/4/8 GPUs', 'value': world * args.batch * args.steps / elapsed,
         'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
@@ -166,7 +205,7 @@ def main():
         result['roofline']['step_conv_tflops'] = step_flops / (elapsed / args.steps) / 1e12
         result['roofline']['step_frac_of_f32_mfma_peak'] = result['roofline']['step_conv_tflops'] / PEAK_F32_MFMA_TFLOPS
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result['cpu_baseline'] = cpu_baseline(args)
+        result['cpu_baseline'] = cpu_baseline_subprocess(args)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -431,7 +431,7 @@ class Net:
         # one split-K slab workspace shared by every weight-gradient launch (they run back to back on one stream)
         ws = torch.empty(max([1] + [r[0] for r in ws_requests]), device=self.device, dtype=torch.float32)
         self.keep.append(ws)
-        for (elems, prob), (dev_t, _), (red, _) in zip(ws_requests, self._wgrad_descs or [], self._pending_reduce):
+        for (elems, prob), (dev_t, _), (red, _) in zip(ws_requests, self._wgrad_descs or [], self._pending_reduce or []):
             prob.ws = ws.data_ptr()
             red.p[0] = ws.data_ptr()
             raw = C.string_at(C.addressof(prob), C.sizeof(prob))
