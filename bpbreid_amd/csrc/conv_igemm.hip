@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void bpb_conv_igemm_kernel(const BpbConvProb* 
     const int Rt = P.Rt, St = P.St, ntaps = Rt * St;
     const bpb_gcf gx = (bpb_gcf)P.x;
     const bpb_gcf gw = (bpb_gcf)P.w;
+    constexpr int NTC = NT * 32;                 // output channels per workgroup
 
     int pixoff[2];   // byte offset of this lane's pixel (per 32-pixel sub-tile) inside the halo tile
 #pragma unroll
@@ -60,10 +61,7 @@ __global__ __launch_bounds__(256) void bpb_conv_igemm_kernel(const BpbConvProb* 
         const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
         pixoff[mt] = (((ti * HH + th * sa) * HWd + tw * sa) * LD) * 4 + (C4 ? 0 : half * 16);
     }
-    const int cout_l = ntile * NT * 32 + l31;
-    int wcol[NT];    // clamped output-channel index for the weight loads (columns >= Cout are never stored)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) wcol[nt] = min(cout_l + nt * 32, Cout - 1) * 4;
+    const int cout_l = ntile * NTC + l31;
 
     f32x16 acc[2][NT];
 #pragma unroll
@@ -79,6 +77,13 @@ __global__ __launch_bounds__(256) void bpb_conv_igemm_kernel(const BpbConvProb* 
     const int total_vec = npix << lvpp;
     const int KG = C4 ? 1 : (CK >> 3);         // 8-channel k-groups per tap inside one chunk
     const int nj = C4 ? ((ntaps + 1) >> 1) : ntaps * KG;
+    // weight tile of the chunk in LDS: [tap][CK/4][NTC][4] floats, placed behind the halo image.  Both MFMA operands
+    // then come from LDS (in-order ds_read returns -> counted lgkmcnt waits), never from a global load in the k-loop.
+    float* sB = smem + ((npix * LD + 3) & ~3);
+    const int qn = CK >> 2;
+    const int tapB = qn * NTC * 16;            // bytes per tap in sB
+    const int nB = (ntaps + (C4 ? 1 : 0)) * qn * NTC;   // float4 slots (C4: one extra zero tap for the phantom half)
+    const int boff_lane = (C4 ? 0 : half * NTC * 16) + l31 * 16;
 
     for (int cb = 0; cb < Cin; cb += CK) {
         __syncthreads();   // all waves are done reading the previous chunk
@@ -95,37 +100,46 @@ __global__ __launch_bounds__(256) void bpb_conv_igemm_kernel(const BpbConvProb* 
                 val = BPB_GLD4(gx + (((size_t)n * P.Hi + ih) * P.Wi + iw) * Cin + cb + v * 4);
             *(f32x4*)(smem + hp * LD + v * 4) = val;
         }
+        for (int idx = threadIdx.x; idx < nB; idx += 256) {
+            const int n = idx & (NTC - 1);
+            const int r = idx / NTC;
+            const int q = r & (qn - 1);
+            const int t = r >> lvpp;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (t < ntaps) {
+                const int ti_ = t / St, tj_ = t - ti_ * St;
+                const int widx = P.w0 + P.wrs * ti_ + P.wss * tj_;
+                const int co = min(ntile * NTC + n, Cout - 1);     // columns >= Cout are never stored
+                val = BPB_GLD4(gw + ((size_t)(widx * cin4 + (cb >> 2) + q) * Cout + co) * 4);
+            }
+            *(f32x4*)(sB + idx * 4) = val;
+        }
         __syncthreads();
 
-        // scalar iteration state over (tap row i, tap col jj, k-group kg); no table, no memory access
-        int it_i = 0, it_j = 0, it_kg = 0, it_c4 = 0;
+        // scalar iteration state over (tap row i, tap col jj, k-group kg); no table, no global memory access
+        int it_i = 0, it_j = 0, it_kg = 0, it_t = 0, it_c4 = 0;
         auto fetch = [&](f32x4 (&a)[2], f32x4 (&b)[NT]) {
-            int ldsoff, wq;
-            bool bvalid = true;
-            if (C4) {   // Cin == 4: lanes 0-31 take tap 2j, lanes 32-63 tap 2j+1 (phantom tap -> zero weights)
+            int ldsoff, bo;
+            if (C4) {   // Cin == 4: lanes 0-31 take tap 2j, lanes 32-63 tap 2j+1 (phantom tap -> the zero slot)
                 int t = 2 * it_c4 + half;
-                if (t >= ntaps) { t = 2 * it_c4; bvalid = false; }
+                bo = t * tapB;
+                if (t >= ntaps) t = 2 * it_c4;
                 const int ti_ = t / St, tj_ = t - ti_ * St;
                 ldsoff = (((P.dh0 + P.dhs * ti_) * HWd + (P.dw0 + P.dws * tj_)) * LD) * 4;
-                wq = (P.w0 + P.wrs * ti_ + P.wss * tj_) * cin4;
                 ++it_c4;
             } else {
                 ldsoff = (((P.dh0 + P.dhs * it_i) * HWd + (P.dw0 + P.dws * it_j)) * LD + it_kg * 8) * 4;
-                wq = (P.w0 + P.wrs * it_i + P.wss * it_j) * cin4 + (cb >> 2) + it_kg * 2 + half;
+                bo = it_t * tapB + it_kg * 2 * NTC * 16;
                 if (++it_kg == KG) {
                     it_kg = 0;
+                    ++it_t;
                     if (++it_j == St) { it_j = 0; ++it_i; }
                 }
             }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) a[mt] = *(const f32x4*)((const char*)smem + pixoff[mt] + ldsoff);
-            const bpb_gcf wp = gw + (size_t)wq * Cout * 4;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                f32x4 bv = BPB_GLD4(wp + wcol[nt]);
-                if (C4 && !bvalid) bv = f32x4{0.f, 0.f, 0.f, 0.f};
-                b[nt] = bv;
-            }
+            for (int nt = 0; nt < NT; ++nt) b[nt] = *(const f32x4*)((const char*)sB + bo + boff_lane + nt * 32 * 16);
         };
         auto mma = [&](const f32x4 (&a)[2], const f32x4 (&b)[NT]) {
 #pragma unroll
@@ -135,7 +149,7 @@ __global__ __launch_bounds__(256) void bpb_conv_igemm_kernel(const BpbConvProb* 
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA32(a[mt][i], b[nt][i], acc[mt][nt]);
         };
-        // ping-pong operand sets: the loads of k-group j+1 are in flight while the 8*NT MFMAs of k-group j run
+        // ping-pong operand sets: the LDS reads of k-group j+1 are in flight while the 8*NT MFMAs of k-group j run
         f32x4 a0[2], b0[NT], a1[2], b1[NT];
         if (nj > 0) fetch(a0, b0);   // nj == 0: empty tap set (a parity class of a strided 1x1 dgrad) -> zeros
         for (int j = 0; j < nj; j += 2) {
@@ -225,7 +239,7 @@ __global__ __launch_bounds__(256) void bpb_conv_igemm_kernel(const BpbConvProb* 
 // ---------------------------------------------------------------------------------------
 
 template <int TG, int NTW>   // TG = taps per group (9 for spatial filters, 1 for 1x1), NTW = 32-wide co sub-tiles
-__global__ __launch_bounds__(256) void bpb_conv_wgrad_kernel(const BpbWgradProb* __restrict__ probs, int nprobs)
+__global__ __launch_bounds__(256, 2) void bpb_conv_wgrad_kernel(const BpbWgradProb* __restrict__ probs, int nprobs)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int bid = blockIdx.x;
@@ -357,18 +371,28 @@ __global__ __launch_bounds__(256) void bpb_conv_wgrad_kernel(const BpbWgradProb*
 }
 
 // dW[co][ci_real][t] (OIHW, the state-dict layout) (+)= sum_split ws[split][t][ci][co]
-__global__ void bpb_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int T,
-                                        int Cin, int Cin_real, int Cout, int accumulate)
+// block = 64 consecutive slab elements (co fastest -> coalesced 256-B reads) x 4 split lanes; fixed summation order.
+__global__ __launch_bounds__(256) void bpb_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int T,
+                                                               int Cin, int Cin_real, int Cout, int accumulate)
 {
-    const long total = (long)T * Cin_real * Cout;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int co = (int)(i % Cout);
-        const long r = i / Cout;
-        const int ci = (int)(r % Cin_real), t = (int)(r / Cin_real);
-        float s = 0.f;
-        for (int sp = 0; sp < nsplit; ++sp) s += ws[(((size_t)sp * T + t) * Cin + ci) * Cout + co];
-        const size_t o = ((size_t)co * Cin_real + ci) * T + t;
-        dw[o] = accumulate ? dw[o] + s : s;
+    __shared__ float red[4][64];
+    const long total = (long)T * Cin * Cout;
+    const long e = blockIdx.x * 64L + (threadIdx.x & 63);
+    const int sl = threadIdx.x >> 6;
+    float s = 0.f;
+    if (e < total)
+        for (int sp = sl; sp < nsplit; sp += 4) s += ws[(size_t)sp * total + e];
+    red[sl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sl == 0 && e < total) {
+        s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        const int co = (int)(e % Cout);
+        const long r = e / Cout;
+        const int ci = (int)(r % Cin), t = (int)(r / Cin);
+        if (ci < Cin_real) {
+            const size_t o = ((size_t)co * Cin_real + ci) * T + t;
+            dw[o] = accumulate ? dw[o] + s : s;
+        }
     }
 }
 
@@ -417,7 +441,9 @@ __global__ void bpb_pack_weights_kernel(const BpbPackProb* __restrict__ probs, i
 static int conv_lds_bytes(const BpbConvProb& p)
 {
     const int npix = (1 << p.lTI) * p.HH * p.HW;
-    int b = npix * p.LD * 4;
+    const int nt = p.Cout <= 32 ? 1 : 2;
+    const int ntaps = p.Rt * p.St + (p.Cin == 4 ? 1 : 0);
+    int b = ((npix * p.LD + 3) & ~3) * 4 + ntaps * (p.CK / 4) * nt * 32 * 16;   // halo image + weight tile
     return b < 8192 ? 8192 : b;
 }
 
@@ -521,10 +547,9 @@ int bpb_conv_wgrad(const BpbWgradProb* d_probs, const BpbWgradProb* h_probs, int
 int bpb_wgrad_reduce(const float* ws, float* dw, int nsplit, int T, int Cin, int Cin_real, int Cout, int accumulate,
                      hipStream_t stream)
 {
-    const long total = (long)T * Cin_real * Cout;
-    BPB_REQUIRE(total > 0 && nsplit >= 1, "bpb_wgrad_reduce: empty problem");
-    int grid = bpb_cdiv(total, 256);
-    if (grid > 2048) grid = 2048;
+    const long total = (long)T * Cin * Cout;
+    BPB_REQUIRE(total > 0 && nsplit >= 1 && Cin_real <= Cin, "bpb_wgrad_reduce: empty problem");
+    const int grid = bpb_cdiv(total, 64);
     hipLaunchKernelGGL(bpb_wgrad_reduce_kernel, dim3(grid), dim3(256), 0, stream, ws, dw, nsplit, T, Cin, Cin_real, Cout,
                        accumulate);
     BPB_LAUNCH_OK();

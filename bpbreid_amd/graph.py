@@ -196,6 +196,9 @@ class Net:
         ti, th, tw = choose_tile(n, a, b, tile_pixels)
         hh = (th - 1) * sa + span_h + 1
         hw = (tw - 1) * sa + span_w + 1
+        ntc = 32 if cout <= 32 else 64
+        ntaps_b = rt * st + (1 if cin == 4 else 0)
+        lds_bytes = lambda ck_, ld_: ((ti * hh * hw * ld_ + 3) // 4 * 4) * 4 + ntaps_b * (ck_ // 4) * ntc * 16
         if cin == 4:
             ck, ld = 4, 4
         else:
@@ -203,10 +206,11 @@ class Net:
             while cin % ck:
                 ck //= 2
             assert ck >= 8, 'Cin must be 4 or a multiple of 8'
-            while ck > 8 and ti * hh * hw * (ck + 4) * 4 > 64 * 1024:
+            # halo image + weight tile of one channel chunk: keep two workgroups resident per CU (160 KiB LDS)
+            while ck > 8 and lds_bytes(ck, ck + 4) > 78 * 1024:
                 ck //= 2
             ld = ck + 4
-        assert ti * hh * hw * ld * 4 <= 160 * 1024, 'conv halo tile exceeds LDS'
+        assert lds_bytes(ck, ld) <= 160 * 1024, 'conv tile (halo + weights) exceeds LDS'
         p = ConvProb()
         p.x, p.w, p.y = x_buf.data_ptr(), w_packed.data_ptr(), y_buf.data_ptr()
         p.bias = bias.data_ptr() if bias is not None else None
@@ -467,7 +471,7 @@ class Net:
         wp.n_cotiles = -(-cout // (32 * ntw))
         wp.n_tapgroups = 1 if t == 1 else -(-t // 9)
         pairs = wp.n_citiles * wp.n_cotiles * wp.n_tapgroups
-        wp.nsplit = max(1, min(wp.n_mtiles, -(-768 // pairs)))
+        wp.nsplit = max(1, min(-(-wp.n_mtiles // 2), -(-512 // pairs)))
         wp.blk_begin = 0
         wp.magic_hw, wp.magic_hh = magic(wp.HW), magic(wp.HH)
         lds = ((1 << wp.lTI) * wp.HH * wp.HW * wp.LD) * 4 + 128 * 32 * ntw * 4
