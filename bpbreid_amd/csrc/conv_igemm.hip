@@ -52,16 +52,22 @@ __global__ __launch_bounds__(256) void bpb_conv_igemm_kernel(const BpbConvProb* 
     const int Rt = P.Rt, St = P.St, ntaps = Rt * St;
     const bpb_gcf gx = (bpb_gcf)P.x;
     const bpb_gcf gw = (bpb_gcf)P.w;
-    constexpr int NTC = NT * 32;                 // output channels per workgroup
+    // Workgroup tile = (WM * MT * 32 pixels) x (WN * NT * 32 channels) with WM * WN = 4 waves.  MT in {1,2} and WN in {1,2}
+    // are per-problem (runtime, wave-uniform): small tiles give the deep, low-resolution HRNet branches enough
+    // workgroups to occupy 256 CUs (a 256-channel 8x4 map at batch 64 is only eight 256-pixel tiles).
+    const int MTr = P.mt_r, lwn = P.lwn;
+    const int wm = wave >> lwn, wni = wave & ((1 << lwn) - 1);
+    const int NTC = (NT * 32) << lwn;            // output channels per workgroup
+    const int lNTC = (NT == 1 ? 5 : 6) + lwn;
 
     int pixoff[2];   // byte offset of this lane's pixel (per 32-pixel sub-tile) inside the halo tile
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-        const int m = wave * 64 + mt * 32 + l31;
+        const int m = (wm * MTr + min(mt, MTr - 1)) * 32 + l31;
         const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
         pixoff[mt] = (((ti * HH + th * sa) * HWd + tw * sa) * LD) * 4 + (C4 ? 0 : half * 16);
     }
-    const int cout_l = ntile * NTC + l31;
+    const int cout_l = ntile * NTC + wni * NT * 32 + l31;
 
     f32x16 acc[2][NT];
 #pragma unroll
@@ -83,7 +89,7 @@ __global__ __launch_bounds__(256) void bpb_conv_igemm_kernel(const BpbConvProb* 
     const int qn = CK >> 2;
     const int tapB = qn * NTC * 16;            // bytes per tap in sB
     const int nB = (ntaps + (C4 ? 1 : 0)) * qn * NTC;   // float4 slots (C4: one extra zero tap for the phantom half)
-    const int boff_lane = (C4 ? 0 : half * NTC * 16) + l31 * 16;
+    const int boff_lane = (C4 ? 0 : half * NTC * 16) + (wni * NT * 32 + l31) * 16;
 
     for (int cb = 0; cb < Cin; cb += CK) {
         __syncthreads();   // all waves are done reading the previous chunk
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(256) void bpb_conv_igemm_kernel(const BpbConvProb* 
         }
         for (int idx = threadIdx.x; idx < nB; idx += 256) {
             const int n = idx & (NTC - 1);
-            const int r = idx / NTC;
+            const int r = idx >> lNTC;
             const int q = r & (qn - 1);
             const int t = r >> lvpp;
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
@@ -136,18 +142,21 @@ __global__ __launch_bounds__(256) void bpb_conv_igemm_kernel(const BpbConvProb* 
                     if (++it_j == St) { it_j = 0; ++it_i; }
                 }
             }
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) a[mt] = *(const f32x4*)((const char*)smem + pixoff[mt] + ldsoff);
+            a[0] = *(const f32x4*)((const char*)smem + pixoff[0] + ldsoff);
+            if (MTr > 1) a[1] = *(const f32x4*)((const char*)smem + pixoff[1] + ldsoff);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) b[nt] = *(const f32x4*)((const char*)sB + bo + boff_lane + nt * 32 * 16);
         };
         auto mma = [&](const f32x4 (&a)[2], const f32x4 (&b)[NT]) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                for (int nt = 0; nt < NT; ++nt) acc[0][nt] = MFMA32(a[0][i], b[nt][i], acc[0][nt]);
+                if (MTr > 1) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA32(a[mt][i], b[nt][i], acc[mt][nt]);
+                    for (int nt = 0; nt < NT; ++nt) acc[1][nt] = MFMA32(a[1][i], b[nt][i], acc[1][nt]);
+                }
+            }
         };
         // ping-pong operand sets: the LDS reads of k-group j+1 are in flight while the 8*NT MFMAs of k-group j run
         f32x4 a0[2], b0[NT], a1[2], b1[NT];
@@ -176,10 +185,11 @@ __global__ __launch_bounds__(256) void bpb_conv_igemm_kernel(const BpbConvProb* 
     const bool accum = P.accumulate != 0;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
+        if (mt >= MTr) break;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int m = wave * 64 + mt * 32 + row;
+            const int m = (wm * MTr + mt) * 32 + row;
             const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
             const int n = n0 + ti, a = a0 + th, b = b0 + tw;
             const bool pv = (n < P.N) && (a < P.A) && (b < P.B);
@@ -210,13 +220,14 @@ __global__ __launch_bounds__(256) void bpb_conv_igemm_kernel(const BpbConvProb* 
             }
         }
         __syncthreads();
-        if (threadIdx.x < NT * 32) {
-            const int nt = threadIdx.x >> 5, c = threadIdx.x & 31;
-            const int co = ntile * NT * 32 + nt * 32 + c;
+        if (threadIdx.x < NTC) {
+            const int cw = threadIdx.x / (NT * 32);            // which wave column owns this channel
+            const int nt = (threadIdx.x >> 5) % NT, c = threadIdx.x & 31;
+            const int co = ntile * NTC + threadIdx.x;
             if (co < Cout) {
                 double s = 0.0, q = 0.0;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
+                for (int wr = 0; wr < (4 >> lwn); ++wr) {           // fixed order over the wave rows
+                    const int w = (wr << lwn) + cw;
                     s += red[((w * NT + nt) * 32 + c) * 2 + 0];
                     q += red[((w * NT + nt) * 32 + c) * 2 + 1];
                 }
@@ -441,9 +452,8 @@ __global__ void bpb_pack_weights_kernel(const BpbPackProb* __restrict__ probs, i
 static int conv_lds_bytes(const BpbConvProb& p)
 {
     const int npix = (1 << p.lTI) * p.HH * p.HW;
-    const int nt = p.Cout <= 32 ? 1 : 2;
     const int ntaps = p.Rt * p.St + (p.Cin == 4 ? 1 : 0);
-    int b = ((npix * p.LD + 3) & ~3) * 4 + ntaps * (p.CK / 4) * nt * 32 * 16;   // halo image + weight tile
+    int b = ((npix * p.LD + 3) & ~3) * 4 + ntaps * (p.CK / 4) * ((p.nt * 32) << p.lwn) * 16;   // halo image + weight tile
     return b < 8192 ? 8192 : b;
 }
 
@@ -482,15 +492,17 @@ int bpb_conv_igemm(const BpbConvProb* d_probs, const BpbConvProb* h_probs, int n
         BPB_REQUIRE(p.CK >= 4 && p.CK <= 32 && (p.CK & (p.CK - 1)) == 0 && p.Cin % p.CK == 0 && (p.Cin == 4 || p.CK >= 8),
                     "bpb_conv_igemm: bad channel chunk CK=%d for Cin=%d", p.CK, p.Cin);
         BPB_REQUIRE(p.LD >= p.CK && p.LD % 4 == 0, "bpb_conv_igemm: bad LDS pitch %d", p.LD);
-        BPB_REQUIRE(p.lTI + p.lTH + p.lTW == 8, "bpb_conv_igemm: M tile must be 256 pixels");
+        BPB_REQUIRE((p.mt_r == 1 || p.mt_r == 2) && (p.lwn == 0 || p.lwn == 1), "bpb_conv_igemm: bad tile shape mt=%d lwn=%d", p.mt_r, p.lwn);
+        BPB_REQUIRE((1 << (p.lTI + p.lTH + p.lTW)) == (4 >> p.lwn) * p.mt_r * 32, "bpb_conv_igemm: M tile / wave layout mismatch");
+        BPB_REQUIRE(p.nt == 1 || p.nt == 2, "bpb_conv_igemm: nt=%d", p.nt);
         BPB_REQUIRE(p.Rt >= 0 && p.St >= 0 && p.Rt * p.St <= 64, "bpb_conv_igemm: tap grid %dx%d", p.Rt, p.St);
         BPB_REQUIRE(i == 0 || (p.Cin == 4) == (h_probs[0].Cin == 4), "bpb_conv_igemm: Cin==4 problems need their own group");
         BPB_REQUIRE(p.blk_begin == nblk, "bpb_conv_igemm: blk_begin mismatch");
         BPB_REQUIRE(((uintptr_t)p.x & 15) == 0 && ((uintptr_t)p.w & 15) == 0, "bpb_conv_igemm: x/w must be 16-byte aligned");
-        const int this_nt = p.Cout <= 32 ? 1 : 2;
+        const int this_nt = p.nt;
         BPB_REQUIRE(nt == 0 || nt == this_nt, "bpb_conv_igemm: mixed N-tile widths in one group");
         nt = this_nt;
-        BPB_REQUIRE(p.n_ntiles == bpb_cdiv(p.Cout, 32 * nt), "bpb_conv_igemm: n_ntiles mismatch");
+        BPB_REQUIRE(p.n_ntiles == bpb_cdiv(p.Cout, (32 * nt) << p.lwn), "bpb_conv_igemm: n_ntiles mismatch");
         nblk += p.n_mtiles * p.n_ntiles;
         const int l = conv_lds_bytes(p);
         lds = l > lds ? l : lds;

@@ -193,10 +193,25 @@ class Net:
         rt, st = taps[0], taps[1]
         span_h = max(0, rt - 1)
         span_w = max(0, st - 1)
-        ti, th, tw = choose_tile(n, a, b, tile_pixels)
+        # ---- tile shape: (pixels, channels) per workgroup.  Largest tile that still yields >= ~1.5 workgroups per CU;
+        # otherwise the shape with the most workgroups (deep, low-resolution branches).
+        cands = [(2, 0, 2), (2, 0, 1), (1, 0, 2), (1, 0, 1), (1, 1, 1)] if cout > 32 else [(2, 0, 1), (1, 0, 1)]
+        cands = [c for c in cands if ((32 * c[2]) << c[1]) <= max(32, _pow2ceil(cout))]
+        forced = getattr(self, 'force_tile', None)       # tests pin a tile shape to cover every kernel variant
+        if forced is not None and forced in cands:
+            cands = [forced]
+        scored = []
+        for mt_r, lwn, nt in cands:
+            pixels = (4 >> lwn) * mt_r * 32
+            ti_, th_, tw_ = choose_tile(n, a, b, pixels)
+            blocks = (-(-n // ti_)) * (-(-a // th_)) * (-(-b // tw_)) * (-(-cout // ((32 * nt) << lwn)))
+            scored.append((blocks, pixels * ((32 * nt) << lwn), mt_r, lwn, nt, ti_, th_, tw_))
+        ok = [s_ for s_ in scored if s_[0] >= 384]
+        best = max(ok, key=lambda s_: (s_[1], s_[0])) if ok else max(scored, key=lambda s_: (s_[0], s_[1]))
+        _, _, mt_r, lwn, nt, ti, th, tw = best
         hh = (th - 1) * sa + span_h + 1
         hw = (tw - 1) * sa + span_w + 1
-        ntc = 32 if cout <= 32 else 64
+        ntc = (32 * nt) << lwn
         ntaps_b = rt * st + (1 if cin == 4 else 0)
         lds_bytes = lambda ck_, ld_: ((ti * hh * hw * ld_ + 3) // 4 * 4) * 4 + ntaps_b * (ck_ // 4) * ntc * 16
         if cin == 4:
@@ -226,10 +241,10 @@ class Net:
         p.HH, p.HW, p.CK, p.LD = hh, hw, ck, ld
         p.tiles_a, p.tiles_b = -(-a // th), -(-b // tw)
         p.n_mtiles = (-(-n // ti)) * p.tiles_a * p.tiles_b
-        nt = 1 if cout <= 32 else 2
-        p.n_ntiles = -(-cout // (32 * nt))
+        p.n_ntiles = -(-cout // ntc)
         p.blk_begin = 0
         p.accumulate = accumulate
+        p.mt_r, p.lwn, p.nt = mt_r, lwn, nt
         p.magic_hw, p.magic_hh = magic(hw), magic(hh)
         if stats is not None:
             st_buf = torch.empty(p.n_mtiles * 2 * cout, device=self.device, dtype=torch.float64)
@@ -241,8 +256,7 @@ class Net:
     def _emit_conv(self, plans, prob, label):
         dev = self._dev_struct(prob)
         op = self._op(nv.OP_CONV, ints=(1,), ptrs=(dev, C.addressof(prob)))
-        nt = 1 if prob.Cout <= 32 else 2
-        variant = 'bpb_conv_igemm_kernel<%d,%s>' % (nt, 'true' if prob.Cin == 4 else 'false')
+        variant = 'bpb_conv_igemm_kernel<%d,%s>' % (prob.nt, 'true' if prob.Cin == 4 else 'false')
         npix = prob.N * prob.A * prob.B
         flops = 2.0 * npix * prob.Rt * prob.St * prob.Cin * prob.Cout
         bytes_ = 4.0 * (prob.N * prob.Hi * prob.Wi * prob.Cin + npix * prob.Cout)

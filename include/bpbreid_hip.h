@@ -51,12 +51,13 @@ typedef struct BpbConvProb {
     // (ih0, iw0) and uses packed-weight slice w0 + wrs*i + wss*j.  Covers full filters (forward, stride-1 dgrad)
     // and the per-parity tap subsets of strided dgrad without any table lookup in the inner loop.
     int Rt, St, dh0, dhs, dw0, dws, w0, wrs, wss;
-    int lTI, lTH, lTW;      // log2 of the M-tile factorisation TI x TH x TW (= 256 pixels)
+    int lTI, lTH, lTW;      // log2 of the M-tile factorisation TI x TH x TW (= (4 >> lwn) * mt_r * 32 pixels)
     int HH, HW;             // halo tile dims
     int CK, LD;             // channel chunk staged per pass and LDS row pitch (floats)
     int tiles_a, tiles_b, n_mtiles, n_ntiles;
     int blk_begin;          // first blockIdx of this problem inside a grouped launch
     int accumulate;         // y += result
+    int mt_r, lwn, nt;      // wave tile: mt_r 32-pixel sub-tiles (1|2), 2^lwn waves along channels (lwn 0|1), nt 32-channel sub-tiles (1|2)
     unsigned magic_hw, magic_hh;   // ceil(2^32/d) for d = HW, HH (staging index split without idiv)
 } BpbConvProb;
 

@@ -34,7 +34,8 @@ def pack_dgrad(w, cin_pad):
 def run_conv(p, x, wpk, y, bias=None):
     """p: object with the ConvProb fields; x [N,Hi,Wi,Cin], wpk flat packed weights, y [N,Ho,Wo,Cout] (in/out)."""
     ti_n, th_n, tw_n = 1 << p.lTI, 1 << p.lTH, 1 << p.lTW
-    assert ti_n * th_n * tw_n == 256
+    mt = ti_n * th_n * tw_n
+    assert mt == (4 >> p.lwn) * p.mt_r * 32 and p.n_ntiles == -(-p.Cout // ((32 * p.nt) << p.lwn))
     cin, cout, ld = p.Cin, p.Cout, p.LD
     cin4 = cin // 4
 
@@ -46,8 +47,8 @@ def run_conv(p, x, wpk, y, bias=None):
         t2 = mtile // p.tiles_b
         ta, tn = t2 % p.tiles_a, t2 // p.tiles_a
         n0, a0, b0 = tn << p.lTI, ta << p.lTH, tb << p.lTW
-        acc = np.zeros((256, cout))
-        m = np.arange(256)
+        acc = np.zeros((mt, cout))
+        m = np.arange(mt)
         tw = m & (tw_n - 1)
         th = (m >> p.lTW) & (th_n - 1)
         ti = m >> (p.lTW + p.lTH)
@@ -69,14 +70,14 @@ def run_conv(p, x, wpk, y, bias=None):
                     widx = p.w0 + p.wrs * i + p.wss * j
                     hidx = pix + dh * p.HW + dw
                     assert hidx.max() < halo.shape[0], 'tap reads outside the staged halo'
-                    a = halo[hidx, :p.CK]                               # [256, CK]
+                    a = halo[hidx, :p.CK]                               # [pixels, CK]
                     for c in range(p.CK):
                         ci = cb + c
                         q, e = ci // 4, ci % 4
                         base = ((widx * cin4 + q) * cout) * 4
                         brow = wpk[base + np.arange(cout) * 4 + e]
                         acc += np.outer(a[:, c], brow)
-        for mm in range(256):
+        for mm in range(mt):
             n, a, b = n0 + ti[mm], a0 + th[mm], b0 + tw[mm]
             if n < p.N and a < p.A and b < p.B:
                 v = acc[mm].copy()

@@ -86,13 +86,23 @@ CONV_CASES = [
 ]
 
 
+TILE_VARIANTS = [None, (2, 0, 2), (2, 0, 1), (1, 0, 2), (1, 0, 1), (1, 1, 1)]
+
+
+@pytest.mark.parametrize('tile', TILE_VARIANTS[1:])
+@pytest.mark.parametrize('case', [(4, 32, 16, 64, 64, 3, 1, 1), (3, 33, 17, 32, 128, 3, 2, 1), (2, 24, 8, 96, 48, 1, 1, 0)])
+def test_conv_every_tile_shape(case, tile):
+    test_conv_forward_backward(case, tile)
+
+
 @pytest.mark.parametrize('case', CONV_CASES)
-def test_conv_forward_backward(case):
+def test_conv_forward_backward(case, tile=None):
     n, h, w, cin, cout, k, stride, pad = case
     g = torch.Generator().manual_seed(1000 + sum(case))
     x = torch.randn(n, cin, h, w, generator=g)
     wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
     net = Net(DEV)
+    net.force_tile = tile
     cpad = 4 if cin == 3 else cin
     xa = Act(net, n, h, w, cpad)
     xa.needs_grad = cin != 3
