@@ -74,6 +74,20 @@ def _emit_chain(net, chain, x):
     return x
 
 
+def _emit_parallel_chains(net, chains, xs):
+    """Independent chains (the branches of a module, the head's incre modules) are recorded on separate stream slots
+    between a fork and a join so that low-resolution branches overlap with the high-resolution one."""
+    n = len(chains)
+    net.fork(n)
+    outs = []
+    for i, (chain, x) in enumerate(zip(chains, xs)):
+        net.set_slot(i)
+        outs.append(_emit_chain(net, chain, x))
+    net.set_slot(0)
+    net.join(n)
+    return outs
+
+
 class MultiResModule(nn.Module):
     """HighResolutionModule (hrnet.py:140-279)."""
 
@@ -100,7 +114,7 @@ class MultiResModule(nn.Module):
         self.fuse_layers = nn.ModuleList(rows)
 
     def emit(self, net, xs):
-        xs = [_emit_chain(net, b, x) for b, x in zip(self.branches, xs)]
+        xs = _emit_parallel_chains(net, self.branches, xs)
         # Down-paths of different targets share nothing, up-paths are 1x1 conv + BN whose nearest upsample is
         # folded into the fuse read (no upsampled tensor is ever written).
         outs = []
@@ -182,7 +196,7 @@ class HRNet(nn.Module):
             for mod in getattr(self, 'stage%d' % (s + 2)):
                 xs = mod.emit(net, xs)
             ys = xs
-        ys = [_emit_chain(net, m, y) for m, y in zip(self.incre_modules, ys)]
+        ys = _emit_parallel_chains(net, self.incre_modules, ys)
         return net.concat_bilinear(ys)
 
 

@@ -246,11 +246,15 @@ __global__ __launch_bounds__(256) void bpb_head_bwd_dlogits_kernel(const float* 
                                                                    const unsigned char* __restrict__ argpart,
                                                                    const float* __restrict__ zinv, const float* __restrict__ gp,
                                                                    const float* __restrict__ dlogit_ext,
-                                                                   float* __restrict__ dlogit, int N, int HW, int K1)
+                                                                   float* __restrict__ dlogit, double* __restrict__ lpart,
+                                                                   int N, int HW, int K1)
 {
+    __shared__ double red[256];
     const int J = K1 + 2;        // pooled rows: 0 global, 1 fg, 2 bg, 3.. parts
     const int JD = K1 + 1;       // D rows: fg, bg, parts
     const long total = (long)N * HW;
+    double lsum[BPB_HEAD_MAXJ];
+    for (int k = 0; k < BPB_HEAD_MAXJ; ++k) lsum[k] = 0.0;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
         const long n = i / HW, p = i - n * HW;
         float pr[BPB_HEAD_MAXJ], dp[BPB_HEAD_MAXJ];
@@ -277,7 +281,19 @@ __global__ __launch_bounds__(256) void bpb_head_bwd_dlogits_kernel(const float* 
             float g = pr[k] * (dp[k] - dot);
             if (dlogit_ext) g += dlogit_ext[(n * K1 + k) * HW + p];
             dlogit[(n * K1 + k) * HW + p] = g;
+            lsum[k] += (double)g;
         }
+    }
+    // per-block class sums L_k = sum dlogit_k (consumed by bpb_head_bwd_params: bias gradient, BN backward constants)
+    for (int k = 0; k < K1; ++k) {
+        red[threadIdx.x] = lsum[k];
+        __syncthreads();
+        for (int o = 128; o >= 1; o >>= 1) {
+            if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) lpart[(long)blockIdx.x * K1 + k] = red[0];
+        __syncthreads();
     }
 }
 
@@ -303,7 +319,7 @@ __global__ __launch_bounds__(256) void bpb_rowdot_kernel(const float* __restrict
 //   A = (Araw - mu*L) * invstd ;  S1 = sum_k W[k][c] L[k] ;  S2 = sum_k W[k][c] A[k][c]
 //   dbeta = S1, dgamma = S2, dW[k][c] = gamma*A + beta*L, dbias = L ;  k1 = S1/M, k2 = S2/M
 __global__ __launch_bounds__(256) void bpb_head_bwd_params_kernel(const float* __restrict__ part, int nparts,
-                                                                  const float* __restrict__ dlogit, long npix_total, int HW,
+                                                                  const double* __restrict__ lpart, int nlpart, long npix_total, int HW,
                                                                   int K1, int C, const float* __restrict__ W,
                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -314,14 +330,10 @@ __global__ __launch_bounds__(256) void bpb_head_bwd_params_kernel(const float* _
 {
     __shared__ double L[BPB_HEAD_MAXJ];
     __shared__ double red[256];
-    // every block recomputes L[k] (K1 * N*HW floats, L2 resident) -- deterministic, no cross-block dependency
-    const long per = npix_total / HW;   // images
+    // every block re-sums the per-block class sums (a few thousand doubles) -- deterministic, no cross-block dependency
     for (int k = 0; k < K1; ++k) {
         double s = 0.0;
-        for (long i = threadIdx.x; i < npix_total; i += 256) {
-            const long n = i / HW, p = i - n * HW;
-            s += (double)dlogit[(n * K1 + k) * HW + p];
-        }
+        for (int b = threadIdx.x; b < nlpart; b += 256) s += lpart[(long)b * K1 + k];
         red[threadIdx.x] = s;
         __syncthreads();
         for (int o = 128; o >= 1; o >>= 1) {
@@ -331,7 +343,6 @@ __global__ __launch_bounds__(256) void bpb_head_bwd_params_kernel(const float* _
         if (threadIdx.x == 0) L[k] = red[0];
         __syncthreads();
     }
-    (void)per;
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c < C) {
         const double M = (double)npix_total;
@@ -548,21 +559,26 @@ int bpb_rowdot(const float* a, const float* b, float* out, int rows, int C, hipS
     return 0;
 }
 
+// lpart: (number of blocks = min(4096, ceil(N*HW/256))) * K1 doubles; the block count is returned in *nblocks_out
 int bpb_head_bwd_dlogits(const float* D, const float* probs, const unsigned char* argpart, const float* zinv,
-                         const float* gp, const float* dlogit_ext, float* dlogit, int N, int HW, int K1, hipStream_t stream)
+                         const float* gp, const float* dlogit_ext, float* dlogit, double* lpart, int* nblocks_out, int N,
+                         int HW, int K1, hipStream_t stream)
 {
     BPB_REQUIRE(K1 >= 2 && K1 <= BPB_HEAD_MAXJ - 2, "bpb_head_bwd_dlogits: K+1=%d out of range", K1);
-    hipLaunchKernelGGL(bpb_head_bwd_dlogits_kernel, dim3(head_grid((long)N * HW)), dim3(256), 0, stream, D, probs, argpart,
-                       zinv, gp, dlogit_ext, dlogit, N, HW, K1);
+    const int grid = head_grid((long)N * HW);
+    if (nblocks_out) *nblocks_out = grid;
+    if (!dlogit) return 0;
+    hipLaunchKernelGGL(bpb_head_bwd_dlogits_kernel, dim3(grid), dim3(256), 0, stream, D, probs, argpart,
+                       zinv, gp, dlogit_ext, dlogit, lpart, N, HW, K1);
     BPB_LAUNCH_OK();
     return 0;
 }
 
-int bpb_head_bwd_params(const float* part, int nparts, const float* dlogit, int N, int HW, int K1, int C, const float* W,
+int bpb_head_bwd_params(const float* part, int nparts, const double* lpart, int nlpart, int N, int HW, int K1, int C, const float* W,
                         const float* gamma, const float* beta, const float* mean, const float* invstd, float* dW,
                         float* dbias, float* dgamma, float* dbeta, float* k1, float* k2, int accumulate, hipStream_t stream)
 {
-    hipLaunchKernelGGL(bpb_head_bwd_params_kernel, dim3(bpb_cdiv(C, 256)), dim3(256), 0, stream, part, nparts, dlogit,
+    hipLaunchKernelGGL(bpb_head_bwd_params_kernel, dim3(bpb_cdiv(C, 256)), dim3(256), 0, stream, part, nparts, lpart, nlpart,
                        (long)N * HW, HW, K1, C, W, gamma, beta, mean, invstd, dW, dbias, dgamma, dbeta, k1, k2, accumulate);
     BPB_LAUNCH_OK();
     return 0;

@@ -10,10 +10,68 @@
 
 static int run_one(const BpbPlanOp& o, int k, hipStream_t stream);
 
+// ---- branch-level concurrency -------------------------------------------------------------------------------------
+// The parallel branches of an HRNet module are independent between the module's fork and join points, and the deep
+// low-resolution branches alone cannot fill 256 CUs (a 256-channel 8x4 map at batch 64 yields ~128 workgroups).  Ops carry
+// a stream slot (i[10]); slot 0 is the caller's stream, slots 1..3 are side streams owned by the library.  FORK makes the
+// side streams wait for the main stream, JOIN makes the main stream wait for them (HIP events; also valid under stream
+// capture, so a plan with forks can still be recorded into a hipGraph).
+#define BPB_NSIDE 3
+#define BPB_NEVENTS 64
+static hipStream_t g_side[BPB_NSIDE];
+static hipEvent_t g_events[BPB_NEVENTS];
+static int g_event_next = 0;
+static bool g_streams_ready = false;
+
+static int ensure_streams()
+{
+    if (g_streams_ready) return 0;
+    for (int s = 0; s < BPB_NSIDE; ++s)
+        if (hipStreamCreateWithFlags(&g_side[s], hipStreamNonBlocking) != hipSuccess)
+            return bpb_set_error(1, "bpb_plan_run: cannot create side stream");
+    for (int e = 0; e < BPB_NEVENTS; ++e)
+        if (hipEventCreateWithFlags(&g_events[e], hipEventDisableTiming) != hipSuccess)
+            return bpb_set_error(1, "bpb_plan_run: cannot create event");
+    g_streams_ready = true;
+    return 0;
+}
+
+static hipEvent_t next_event()
+{
+    hipEvent_t e = g_events[g_event_next];
+    g_event_next = (g_event_next + 1) % BPB_NEVENTS;
+    return e;
+}
+
 extern "C" int bpb_plan_run(const BpbPlanOp* ops, int nops, hipStream_t stream)
 {
     for (int k = 0; k < nops; ++k) {
-        const int rc = run_one(ops[k], k, stream);
+        const BpbPlanOp& o = ops[k];
+        if (o.kind == BPB_OP_FORK || o.kind == BPB_OP_JOIN) {   // i0 = bit mask of side slots (bit s-1 = slot s)
+            if (int rc = ensure_streams()) return rc;
+            if (o.kind == BPB_OP_FORK) {
+                hipEvent_t e = next_event();
+                (void)hipEventRecord(e, stream);
+                for (int s = 0; s < BPB_NSIDE; ++s)
+                    if (o.i[0] & (1 << s)) (void)hipStreamWaitEvent(g_side[s], e, 0);
+            } else {
+                for (int s = 0; s < BPB_NSIDE; ++s)
+                    if (o.i[0] & (1 << s)) {
+                        hipEvent_t e = next_event();
+                        (void)hipEventRecord(e, g_side[s]);
+                        (void)hipStreamWaitEvent(stream, e, 0);
+                    }
+            }
+            continue;
+        }
+        const int slot = o.i[10];
+        hipStream_t st = stream;
+        if (slot > 0) {
+            if (slot > BPB_NSIDE) return bpb_set_error(-1, "bpb_plan_run: stream slot %d out of range", slot);
+            if (int rc = ensure_streams()) return rc;
+            st = g_side[slot - 1];
+        }
+        const int rc = run_one(o, k, st);
         if (rc != 0) return rc;
     }
     return 0;
@@ -29,8 +87,8 @@ extern "C" int bpb_plan_run_timed(const BpbPlanOp* ops, int nops, hipStream_t st
         if (hipEventCreate(&e) != hipSuccess) return bpb_set_error(1, "bpb_plan_run_timed: hipEventCreate failed");
     (void)hipEventRecord(ev[0], stream);
     int rc = 0;
-    for (int k = 0; k < nops && rc == 0; ++k) {
-        rc = run_one(ops[k], k, stream);
+    for (int k = 0; k < nops && rc == 0; ++k) {     // everything on ONE stream: fork/join records are no-ops here
+        if (ops[k].kind != BPB_OP_FORK && ops[k].kind != BPB_OP_JOIN) rc = run_one(ops[k], k, stream);
         (void)hipEventRecord(ev[k + 1], stream);
     }
     (void)hipStreamSynchronize(stream);

@@ -57,7 +57,10 @@ class PlanList(list):
         super().__init__()
         self.meta = []
 
+    slot = 0     # stream slot stamped on every record that is added (set by the emitter)
+
     def add(self, op, label, flops=0.0, bytes_=0.0):
+        op.i[10] = self.slot
         self.append(op)
         self.meta.append({'label': label, 'flops': float(flops), 'bytes': float(bytes_)})
 
@@ -105,20 +108,40 @@ class Net:
     def __init__(self, device):
         self.device = device
         self.nodes = []            # (kind, payload) in forward order
+        self.node_slots = []       # stream slot of each node
         self.keep = []             # ctypes objects / tensors that must outlive the plans
         self.convs = []
         self.fwd_train, self.fwd_eval, self.bwd = PlanList(), PlanList(), PlanList()
+        self.cur_slot = 0          # stream slot of the nodes being recorded (branch-level concurrency)
         self.debug_convs = []      # (ConvProb, x, packed w, y) -- lets the CPU tests emulate the descriptors
         self.debug_wgrads = []     # (WgradProb, ConvNode)
 
     # ------------------------------------------------------------------ graph construction
+    def _node(self, kind, payload):
+        self.nodes.append((kind, payload))
+        self.node_slots.append(self.cur_slot)
+
+    def fork(self, nslots):
+        """Branches recorded with set_slot(1..nslots-1) may run concurrently with slot 0 until the matching join()."""
+        assert self.cur_slot == 0 and 1 <= nslots <= 4
+        if nslots > 1:
+            self._node('fork', (1 << (nslots - 1)) - 1)
+
+    def join(self, nslots):
+        assert self.cur_slot == 0
+        if nslots > 1:
+            self._node('join', (1 << (nslots - 1)) - 1)
+
+    def set_slot(self, slot):
+        self.cur_slot = slot
+
     def input_nchw(self, n, c, h, w):
         """Boundary: the engine hands NCHW images (part_based_engine.py:347-351); internal layout is NHWC4."""
         self.in_shape = (n, c, h, w)
         self.in_buf = torch.empty(n, c, h, w, device=self.device, dtype=torch.float32)
         x = Act(self, n, h, w, 4)
         x.needs_grad = False
-        self.nodes.append(('input', x))
+        self._node('input', x)
         return x
 
     def conv(self, x, weight, stride, pad, bias=None, bn=None):
@@ -130,7 +153,7 @@ class Net:
         y = Act(self, x.N, ho, wo, cout)
         bnst = BNState(self, cout, *bn) if bn is not None else None
         node = ConvNode(x, y, weight, bias, bnst, r, s, stride, pad, cin_real)
-        self.nodes.append(('conv', node))
+        self._node('conv', node)
         self.convs.append(node)
         return node
 
@@ -142,21 +165,21 @@ class Net:
         for t, up in terms:
             a = t.y if isinstance(t, ConvNode) else t
             assert (a.H << up, a.W << up, a.C) == (out.H, out.W, out.C), 'fuse: term shape mismatch'
-        self.nodes.append(('fuse', (out, list(terms), bool(relu))))
+        self._node('fuse', (out, list(terms), bool(relu)))
         return out
 
     def maxpool(self, x):
         ho, wo = (x.H + 2 - 3) // 2 + 1, (x.W + 2 - 3) // 2 + 1
         y = Act(self, x.N, ho, wo, x.C)
         idx = torch.empty(x.N, ho, wo, x.C, device=self.device, dtype=torch.uint8)
-        self.nodes.append(('maxpool', (x, y, idx)))
+        self._node('maxpool', (x, y, idx))
         return y
 
     def concat_bilinear(self, srcs):
         """hrnet.py:568-573: upsample every map to the first one's resolution and concatenate channels."""
         a0 = srcs[0]
         out = Act(self, a0.N, a0.H, a0.W, sum(a.C for a in srcs))
-        self.nodes.append(('concat', (out, list(srcs))))
+        self._node('concat', (out, list(srcs)))
         return out
 
     # ------------------------------------------------------------------ plan emission helpers
@@ -290,7 +313,13 @@ class Net:
         both = (self.fwd_train, self.fwd_eval)
 
         # ---- forward
-        for kind, pay in self.nodes:
+        for (kind, pay), slot in zip(self.nodes, self.node_slots):
+            self.fwd_train.slot = self.fwd_eval.slot = slot
+            if kind in ('fork', 'join'):
+                op = self._op(nv.OP_FORK if kind == 'fork' else nv.OP_JOIN, ints=(pay,))
+                for pl in both:
+                    pl.add(op, kind)
+                continue
             if kind == 'input':
                 n, c, h, w = self.in_shape
                 op = self._op(nv.OP_NCHW_TO_NHWC4, ints=(n, c, h, w), ptrs=(self.in_buf, pay.buf))
@@ -354,6 +383,7 @@ class Net:
                     for pl in both:
                         pl.add(op, 'bilinear_concat_fwd', 0, 4.0 * (a.buf.numel() + a.N * out.H * out.W * a.C))
                     c0 += a.C
+        self.fwd_train.slot = self.fwd_eval.slot = 0
         if train_backward:
             self._emit_backward()
         self.plan_train = self._freeze(self.fwd_train)
@@ -385,7 +415,13 @@ class Net:
         bwd = self.bwd
         # shared split-K workspace for weight gradients (sized while emitting)
         ws_requests = []
-        for kind, pay in reversed(self.nodes):
+        for (kind, pay), slot in zip(reversed(self.nodes), reversed(self.node_slots)):
+            bwd.slot = slot
+            self._bwd_slot = slot
+            if kind in ('fork', 'join'):       # the backward of a join is a fork and vice versa
+                bwd.slot = 0
+                bwd.add(self._op(nv.OP_JOIN if kind == 'fork' else nv.OP_FORK, ints=(pay,)), 'join' if kind == 'fork' else 'fork')
+                continue
             if kind == 'concat':
                 out, srcs = pay
                 c0 = 0
@@ -446,10 +482,15 @@ class Net:
                             4.0 * (x.buf.numel() + 1.25 * y.buf.numel()))
             elif kind == 'conv':
                 self._emit_conv_backward(pay, ws_requests)
-        # one split-K slab workspace shared by every weight-gradient launch (they run back to back on one stream)
-        ws = torch.empty(max([1] + [r[0] for r in ws_requests]), device=self.device, dtype=torch.float32)
-        self.keep.append(ws)
-        for (elems, prob), (dev_t, _), (red, _) in zip(ws_requests, self._wgrad_descs or [], self._pending_reduce or []):
+        # one split-K slab workspace per stream slot (weight-gradient launches of one slot run back to back)
+        bwd.slot = 0
+        wss = {}
+        for elems, prob, slot in ws_requests:
+            wss[slot] = max(wss.get(slot, 1), elems)
+        wss = {slot: torch.empty(n_, device=self.device, dtype=torch.float32) for slot, n_ in wss.items()}
+        self.keep.append(wss)
+        for (elems, prob, slot), (dev_t, _), (red, _) in zip(ws_requests, self._wgrad_descs or [], self._pending_reduce or []):
+            ws = wss[slot]
             prob.ws = ws.data_ptr()
             red.p[0] = ws.data_ptr()
             raw = C.string_at(C.addressof(prob), C.sizeof(prob))
@@ -491,7 +532,7 @@ class Net:
         lds = ((1 << wp.lTI) * wp.HH * wp.HW * wp.LD) * 4 + 128 * 32 * ntw * 4
         assert lds <= 160 * 1024, 'wgrad tile exceeds LDS'
         elems = wp.nsplit * t * x.C * cout
-        ws_requests.append((elems, wp))
+        ws_requests.append((elems, wp, self._bwd_slot))
         dev = self._dev_struct(wp)
         self._wgrad_descs.append((dev, wp))
         self.debug_wgrads.append((wp, cv))

@@ -315,6 +315,10 @@ class _ModelPlan:
         self.gp = f(n, J)
         self.Dd = f(n, HW, K1 + 1)
         self.dlogit = f(n, K1, HW)
+        nlb = C.c_int(0)
+        nv.call('bpb_head_bwd_dlogits', None, None, None, None, None, None, None, None, C.byref(nlb), n, HW, K1, None)
+        self.nlpart = nlb.value
+        self.lpart = torch.empty(self.nlpart * K1, device=device, dtype=torch.float64)
         self.k1, self.k2 = f(Cc), f(Cc)
         m = model
         self.touched = set()
@@ -525,9 +529,10 @@ class _ModelPlan:
         nv.call('bpb_pixel_dots', x.data_ptr(), gp_ptr + Cc * 4, J * Cc, None, self.Dd.data_ptr(), n, HW, Cc, K1 + 1, s())
         gpix = g['pix'].contiguous() if g['pix'] is not None else None
         nv.call('bpb_head_bwd_dlogits', self.Dd.data_ptr(), self.probs.data_ptr(), self.argpart.data_ptr(), self.zinv.data_ptr(),
-                self.gp.data_ptr(), gpix.data_ptr() if gpix is not None else None, self.dlogit.data_ptr(), n, HW, K1, s())
+                self.gp.data_ptr(), gpix.data_ptr() if gpix is not None else None, self.dlogit.data_ptr(), self.lpart.data_ptr(),
+                None, n, HW, K1, s())
         nv.call('bpb_masked_pool', x.data_ptr(), self.dlogit.data_ptr(), self.pool_part.data_ptr(), n, HW, Cc, K1, None, s())
-        nv.call('bpb_head_bwd_params', self.pool_part.data_ptr(), n * self.nchunks, self.dlogit.data_ptr(), n, HW, K1, Cc,
+        nv.call('bpb_head_bwd_params', self.pool_part.data_ptr(), n * self.nchunks, self.lpart.data_ptr(), self.nlpart, n, HW, K1, Cc,
                 pc.classifier.weight.data_ptr(), pc.bn.weight.data_ptr(), pc.bn.bias.data_ptr(), self.pix_mean.data_ptr(),
                 self.pix_invstd.data_ptr(), pc.classifier.weight.grad.data_ptr(), pc.classifier.bias.grad.data_ptr(),
                 pc.bn.weight.grad.data_ptr(), pc.bn.bias.grad.data_ptr(), self.k1.data_ptr(), self.k2.data_ptr(), 0, s())

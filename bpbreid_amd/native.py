@@ -61,7 +61,7 @@ class PlanOp(C.Structure):
 
 (OP_CONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL_AFFINE, OP_FUSE_FWD, OP_TERM_BWD,
  OP_BN_BWD_FINALIZE, OP_NCHW_TO_NHWC4, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_BILINEAR_FWD, OP_BILINEAR_BWD, OP_FILL,
- OP_CHANNEL_STATS) = range(16)
+ OP_CHANNEL_STATS, OP_FORK, OP_JOIN) = range(18)
 
 
 def magic(d):
@@ -139,8 +139,8 @@ PROTOS = {
     'bpb_bilinear_concat_fwd': 'pp', 'bpb_bilinear_concat_bwd': 'ppp',
     'bpb_pixel_dots': 'pplppiiiip', 'bpb_masked_pool': 'pppiiiipp', 'bpb_fold_bn': 'ppppppiip',
     'bpb_softmax_masks': 'ppppppiiip', 'bpb_visibility': 'ppppiiiip', 'bpb_pool_finalize': 'ppppiiiiip',
-    'bpb_rowdot': 'pppiip', 'bpb_head_bwd_dlogits': 'pppppppiiip',
-    'bpb_head_bwd_params': 'pipiiiipppppppppppip', 'bpb_head_bwd_dx': 'ppppppppppppiiiiip',
+    'bpb_rowdot': 'pppiip', 'bpb_head_bwd_dlogits': 'pppppppppiiip',
+    'bpb_head_bwd_params': 'pipiiiiipppppppppppip', 'bpb_head_bwd_dx': 'ppppppppppppiiiiip',
     'bpb_gemm': 'pllpllplpiiiippp', 'bpb_colsum': 'ppiiip',
     'bpb_bn1d_fwd': 'plpliippppppffiip', 'bpb_bn1d_bwd': 'plplplpliipppppiip',
     'bpb_ce_label_smooth': 'plpipiiifppplpp', 'bpb_pixel_ce': 'ppiiiiiifppipp',

@@ -144,9 +144,11 @@ typedef enum BpbOpKind {
     BPB_OP_BILINEAR_BWD = 13,
     BPB_OP_FILL = 14,
     BPB_OP_CHANNEL_STATS = 15,
+    BPB_OP_FORK = 16,
+    BPB_OP_JOIN = 17,
 } BpbOpKind;
 
-// generic op record; slot meaning per kind is documented next to each case
+// generic op record; slot meaning per kind is documented next to each case; i[10] = stream slot (0 main, 1..3 side)
 typedef struct BpbPlanOp {
     int kind;
     int i[11];
@@ -213,8 +215,9 @@ int bpb_pool_finalize(const float* part, const float* pm, float* pooled, float* 
                       int C, hipStream_t stream);
 int bpb_rowdot(const float* a, const float* b, float* out, int rows, int C, hipStream_t stream);
 int bpb_head_bwd_dlogits(const float* D, const float* probs, const unsigned char* argpart, const float* zinv,
-                         const float* gp, const float* dlogit_ext, float* dlogit, int N, int HW, int K1, hipStream_t stream);
-int bpb_head_bwd_params(const float* part, int nparts, const float* dlogit, int N, int HW, int K1, int C, const float* W,
+                         const float* gp, const float* dlogit_ext, float* dlogit, double* lpart, int* nblocks_out, int N,
+                         int HW, int K1, hipStream_t stream);
+int bpb_head_bwd_params(const float* part, int nparts, const double* lpart, int nlpart, int N, int HW, int K1, int C, const float* W,
                         const float* gamma, const float* beta, const float* mean, const float* invstd, float* dW,
                         float* dbias, float* dgamma, float* dbeta, float* k1, float* k2, int accumulate, hipStream_t stream);
 int bpb_head_bwd_dx(const float* x, const float* G, const float* pm, const float* zinv, const float* dlogit, const float* W,

@@ -71,7 +71,7 @@ def test_conv_descriptors_forward_dgrad_wgrad(case):
     x = Act(net, n, h, w, cpad)
     x.needs_grad = cin != 3
     node = net.conv(x, wt_param, stride, pad, bn=None)
-    net.nodes.append(('fuse', (Act(net, node.y.N, node.y.H, node.y.W, node.y.C), [(node.y, 0)], False)))
+    net._node('fuse', (Act(net, node.y.N, node.y.H, node.y.W, node.y.C), [(node.y, 0)], False))
     net.finalize(train_backward=True)
     # ---- forward
     x_nhwc = np.zeros((n, h, w, cpad))
