@@ -179,6 +179,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = eng.forward_backward(data)
+    host_enqueue = time.perf_counter() - t0         # host time to enqueue all steps (no sync inside the loop)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -196,7 +197,8 @@ def main():
         'config': {'workload': '%s K=%d parts, %dx%d, batch %d per GPU (global %d), GiLt part-triplet + ID loss + pixel CE with '
                                'visibility masks, fwd+loss+bwd+all-reduce+Adam (BASELINE configs[2]/[3])'
                                % (args.backbone, args.parts, args.height, args.width, args.batch, args.batch * world),
-                   'parallelism': 'dp%d' % world, 'global_batch': args.batch * world, 'final_loss': final_loss},
+                   'parallelism': 'dp%d' % world, 'global_batch': args.batch * world, 'final_loss': final_loss,
+                   'host_enqueue_ms_per_step': 1e3 * host_enqueue / args.steps},
     }
     if rank == 0 and world == 1 and not args.no_roofline:
         plan = next(iter(model._plans.values()))

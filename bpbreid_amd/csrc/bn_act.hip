@@ -16,7 +16,7 @@
 // partials: [nparts][2][C] doubles (sum, sumsq).  count = elements per channel.
 // Outputs: scale = gamma*invstd, shift = beta - mean*scale, mean, invstd (saved for backward);
 // running_mean = (1-m)*running_mean + m*mean; running_var uses the unbiased variance (torch semantics).
-__global__ __launch_bounds__(256) void bpb_bn_finalize_kernel(const double* __restrict__ partials, int nparts, int C,
+__global__ __launch_bounds__(1024) void bpb_bn_finalize_kernel(const double* __restrict__ partials, int nparts, int C,
                                                               double count, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float eps, float momentum,
                                                               float* __restrict__ scale, float* __restrict__ shift,
@@ -24,12 +24,12 @@ __global__ __launch_bounds__(256) void bpb_bn_finalize_kernel(const double* __re
                                                               float* __restrict__ running_mean,
                                                               float* __restrict__ running_var)
 {
-    __shared__ double red[2][8][32];
+    __shared__ double red[2][32][32];
     const int c = blockIdx.x * 32 + (threadIdx.x & 31);
-    const int rg = threadIdx.x >> 5;
+    const int rg = threadIdx.x >> 5;      // 32 row groups: the partial rows are summed 32-way in parallel, then in fixed order
     double s = 0.0, q = 0.0;
     if (c < C) {
-        for (int p = rg; p < nparts; p += 8) {
+        for (int p = rg; p < nparts; p += 32) {
             s += partials[((size_t)p * 2 + 0) * C + c];
             q += partials[((size_t)p * 2 + 1) * C + c];
         }
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void bpb_bn_finalize_kernel(const double* __re
         s = 0.0;
         q = 0.0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 32; ++i) {
             s += red[0][i][threadIdx.x];
             q += red[1][i][threadIdx.x];
         }
@@ -295,17 +295,17 @@ __global__ __launch_bounds__(256) void bpb_term_bwd_bn_reduce_kernel(BpbTermBwdA
 
 // BN term, between passes: dbeta = sum G, dgamma = sum G*xhat -> parameter grads (+ optional accumulate)
 // and the per-channel constants c1 = dbeta / M, c2 = dgamma / M for the apply pass.
-__global__ __launch_bounds__(256) void bpb_bn_bwd_finalize_kernel(const double* __restrict__ partials, int nparts, int C,
+__global__ __launch_bounds__(1024) void bpb_bn_bwd_finalize_kernel(const double* __restrict__ partials, int nparts, int C,
                                                                   double count, float* __restrict__ dgamma,
                                                                   float* __restrict__ dbeta, int accumulate,
                                                                   float* __restrict__ c1, float* __restrict__ c2)
 {
-    __shared__ double red[2][8][32];
+    __shared__ double red[2][32][32];
     const int c = blockIdx.x * 32 + (threadIdx.x & 31);
     const int rg = threadIdx.x >> 5;
     double s = 0.0, q = 0.0;
     if (c < C)
-        for (int p = rg; p < nparts; p += 8) {
+        for (int p = rg; p < nparts; p += 32) {
             s += partials[((size_t)p * 2 + 0) * C + c];
             q += partials[((size_t)p * 2 + 1) * C + c];
         }
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void bpb_bn_bwd_finalize_kernel(const double* 
         s = 0.0;
         q = 0.0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 32; ++i) {
             s += red[0][i][threadIdx.x];
             q += red[1][i][threadIdx.x];
         }
@@ -373,7 +373,7 @@ int bpb_bn_finalize(const double* partials, int nparts, int C, double count, con
                     float* running_mean, float* running_var, hipStream_t stream)
 {
     BPB_REQUIRE(nparts >= 1 && C >= 1 && count >= 1.0, "bpb_bn_finalize: bad sizes");
-    hipLaunchKernelGGL(bpb_bn_finalize_kernel, dim3(bpb_cdiv(C, 32)), dim3(256), 0, stream, partials, nparts, C, count,
+    hipLaunchKernelGGL(bpb_bn_finalize_kernel, dim3(bpb_cdiv(C, 32)), dim3(1024), 0, stream, partials, nparts, C, count,
                        gamma, beta, eps, momentum, scale, shift, mean, invstd, running_mean, running_var);
     BPB_LAUNCH_OK();
     return 0;
@@ -436,7 +436,7 @@ int bpb_bn_bwd_finalize(const double* partials, int nparts, int C, double count,
                         int accumulate, float* c1, float* c2, hipStream_t stream)
 {
     BPB_REQUIRE(nparts >= 1 && C >= 1, "bpb_bn_bwd_finalize: bad sizes");
-    hipLaunchKernelGGL(bpb_bn_bwd_finalize_kernel, dim3(bpb_cdiv(C, 32)), dim3(256), 0, stream, partials, nparts, C,
+    hipLaunchKernelGGL(bpb_bn_bwd_finalize_kernel, dim3(bpb_cdiv(C, 32)), dim3(1024), 0, stream, partials, nparts, C,
                        count, dgamma, dbeta, accumulate, c1, c2);
     BPB_LAUNCH_OK();
     return 0;

@@ -80,47 +80,91 @@ __global__ __launch_bounds__(256) void bpb_conv_igemm_kernel(const BpbConvProb* 
     const int CK = P.CK;                       // power of two in {4, 8, 16, 32}; divides Cin
     const int lvpp = 31 - __clz(CK) - 2;       // log2(CK / 4)
     const int npix = (1 << lTI) * HH * HWd;
-    const int total_vec = npix << lvpp;
     const int KG = C4 ? 1 : (CK >> 3);         // 8-channel k-groups per tap inside one chunk
     const int nj = C4 ? ((ntaps + 1) >> 1) : ntaps * KG;
-    // weight tile of the chunk in LDS: [tap][CK/4][NTC][4] floats, placed behind the halo image.  Both MFMA operands
-    // then come from LDS (in-order ds_read returns -> counted lgkmcnt waits), never from a global load in the k-loop.
-    float* sB = smem + ((npix * LD + 3) & ~3);
+    // LDS image of one channel chunk ("slots" of 16 bytes):
+    //   halo   [halo pixel][spp slots]   spp = LD/4 = CK/4 data slots (+1 pad slot unless Cin == 4)
+    //   weight [tap][CK/4][NTC]          placed behind the halo region; both regions padded to 256 slots
+    // Both MFMA operands come from LDS (in-order ds_read returns -> counted lgkmcnt waits).
     const int qn = CK >> 2;
-    const int tapB = qn * NTC * 16;            // bytes per tap in sB
-    const int nB = (ntaps + (C4 ? 1 : 0)) * qn * NTC;   // float4 slots (C4: one extra zero tap for the phantom half)
-    const int boff_lane = (C4 ? 0 : half * NTC * 16) + (wni * NT * 32 + l31) * 16;
+    const int spp = LD >> 2;
+    const int halo_slots = npix * spp;
+    const int halo_pad = (halo_slots + 255) & ~255;
+    const int nB = (ntaps + (C4 ? 1 : 0)) * qn * NTC;   // (C4: one extra zero tap for the phantom half)
+    const int b_pad = (nB + 255) & ~255;
+    const int bufbytes = (halo_pad + b_pad) * 16;
+    const int tapB = qn * NTC * 16;            // bytes per tap in the weight region
+    const int boff_lane = halo_pad * 16 + (C4 ? 0 : half * NTC * 16) + (wni * NT * 32 + l31) * 16;
+    const bool dma = P.dma != 0;
 
-    for (int cb = 0; cb < Cin; cb += CK) {
-        __syncthreads();   // all waves are done reading the previous chunk
-        for (int idx = threadIdx.x; idx < total_vec; idx += 256) {
-            const int v = idx & ((1 << lvpp) - 1);
-            const unsigned hp = (unsigned)idx >> lvpp;
-            const unsigned t = bpb_fdiv(hp, HWd, P.magic_hw);
-            const int hc = hp - t * HWd;
-            const unsigned ti = bpb_fdiv(t, HH, P.magic_hh);
-            const int hr = t - ti * HH;
-            const int n = n0 + (int)ti, ih = a0 * sa + hr + P.ih0, iw = b0 * sa + hc + P.iw0;
+    // byte offset of slot `idx` of chunk `cb` inside x / w; 0xFFFFFFF0 = "out of range" (buffer loads return 0 there)
+    auto halo_voff = [&](int idx, int cb) -> unsigned {
+        const unsigned hp = bpb_fdiv((unsigned)idx, spp, P.magic_spp);
+        const int v = idx - hp * spp;
+        if (idx >= halo_slots || v >= qn) return 0xFFFFFFF0u;
+        const unsigned t = bpb_fdiv(hp, HWd, P.magic_hw);
+        const int hc = hp - t * HWd;
+        const unsigned ti = bpb_fdiv(t, HH, P.magic_hh);
+        const int hr = t - ti * HH;
+        const int n = n0 + (int)ti, ih = a0 * sa + hr + P.ih0, iw = b0 * sa + hc + P.iw0;
+        if (n < P.N && (unsigned)ih < (unsigned)P.Hi && (unsigned)iw < (unsigned)P.Wi)
+            return ((((unsigned)n * P.Hi + ih) * P.Wi + iw) * Cin + cb + v * 4) * 4u;
+        return 0xFFFFFFF0u;
+    };
+    auto b_voff = [&](int bi, int cb) -> unsigned {
+        const int n = bi & (NTC - 1);
+        const int r = bi >> lNTC;
+        const int q = r & (qn - 1);
+        const int t = r >> lvpp;
+        if (bi >= nB || t >= ntaps) return 0xFFFFFFF0u;
+        const int ti_ = t / St, tj_ = t - ti_ * St;
+        const int widx = P.w0 + P.wrs * ti_ + P.wss * tj_;
+        const int co = min(ntile * NTC + n, Cout - 1);     // columns >= Cout are never stored
+        return (((unsigned)(widx * cin4 + (cb >> 2) + q) * Cout + co) * 4) * 4u;
+    };
+    // (a) asynchronous path: buffer_load ... lds (global -> LDS DMA, no staging registers), double-buffered so that the
+    //     image of chunk c+1 streams in while the MFMA loop of chunk c runs.  One barrier per chunk.
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)P.x, 0, (int)P.x_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)P.w, 0, (int)P.w_bytes, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    auto dma_issue = [&](int cb, int buf) {
+        char* base = (char*)smem + buf * bufbytes + wave * 1024;     // wave-uniform; lanes land at +16*lane
+        for (int b0s = 0; b0s < halo_pad; b0s += 256)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(base + b0s * 16), 16,
+                                                     (int)halo_voff(b0s + (int)threadIdx.x, cb), 0, 0, 0);
+        for (int b0s = 0; b0s < b_pad; b0s += 256)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(base + (halo_pad + b0s) * 16), 16,
+                                                     (int)b_voff(b0s + (int)threadIdx.x, cb), 0, 0, 0);
+    };
+    // (b) synchronous path (fallback when the double-buffered image does not fit in LDS)
+    auto sync_stage = [&](int cb) {
+        for (int idx = threadIdx.x; idx < halo_pad; idx += 256) {
+            const unsigned vo = halo_voff(idx, cb);
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (n < P.N && (unsigned)ih < (unsigned)P.Hi && (unsigned)iw < (unsigned)P.Wi)
-                val = BPB_GLD4(gx + (((size_t)n * P.Hi + ih) * P.Wi + iw) * Cin + cb + v * 4);
-            *(f32x4*)(smem + hp * LD + v * 4) = val;
+            if (vo != 0xFFFFFFF0u) val = BPB_GLD4((const char BPB_GLOBAL*)P.x + vo);
+            *(f32x4*)((char*)smem + idx * 16) = val;
         }
-        for (int idx = threadIdx.x; idx < nB; idx += 256) {
-            const int n = idx & (NTC - 1);
-            const int r = idx >> lNTC;
-            const int q = r & (qn - 1);
-            const int t = r >> lvpp;
+        for (int bi = threadIdx.x; bi < b_pad; bi += 256) {
+            const unsigned vo = b_voff(bi, cb);
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (t < ntaps) {
-                const int ti_ = t / St, tj_ = t - ti_ * St;
-                const int widx = P.w0 + P.wrs * ti_ + P.wss * tj_;
-                const int co = min(ntile * NTC + n, Cout - 1);     // columns >= Cout are never stored
-                val = BPB_GLD4(gw + ((size_t)(widx * cin4 + (cb >> 2) + q) * Cout + co) * 4);
-            }
-            *(f32x4*)(sB + idx * 4) = val;
+            if (vo != 0xFFFFFFF0u) val = BPB_GLD4((const char BPB_GLOBAL*)P.w + vo);
+            *(f32x4*)((char*)smem + (halo_pad + bi) * 16) = val;
         }
-        __syncthreads();
+    };
+
+    if (dma) dma_issue(0, 0);
+    int chunk = 0;
+    for (int cb = 0; cb < Cin; cb += CK, ++chunk) {
+        __syncthreads();   // dma: chunk `chunk` has landed (the barrier drains vmcnt) and the other buffer is free again
+        int bufoff = 0;
+        if (dma) {
+            bufoff = (chunk & 1) * bufbytes;
+            if (cb + CK < Cin) dma_issue(cb + CK, (chunk + 1) & 1);
+        } else {
+            sync_stage(cb);
+            __syncthreads();
+        }
+        const char* sA = (const char*)smem + bufoff;
 
         // scalar iteration state over (tap row i, tap col jj, k-group kg); no table, no global memory access
         int it_i = 0, it_j = 0, it_kg = 0, it_t = 0, it_c4 = 0;
@@ -142,10 +186,10 @@ __global__ __launch_bounds__(256) void bpb_conv_igemm_kernel(const BpbConvProb* 
                     if (++it_j == St) { it_j = 0; ++it_i; }
                 }
             }
-            a[0] = *(const f32x4*)((const char*)smem + pixoff[0] + ldsoff);
-            if (MTr > 1) a[1] = *(const f32x4*)((const char*)smem + pixoff[1] + ldsoff);
+            a[0] = *(const f32x4*)(sA + pixoff[0] + ldsoff);
+            if (MTr > 1) a[1] = *(const f32x4*)(sA + pixoff[1] + ldsoff);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b[nt] = *(const f32x4*)((const char*)sB + bo + boff_lane + nt * 32 * 16);
+            for (int nt = 0; nt < NT; ++nt) b[nt] = *(const f32x4*)(sA + bo + boff_lane + nt * 32 * 16);
         };
         auto mma = [&](const f32x4 (&a)[2], const f32x4 (&b)[NT]) {
 #pragma unroll
@@ -453,7 +497,9 @@ static int conv_lds_bytes(const BpbConvProb& p)
 {
     const int npix = (1 << p.lTI) * p.HH * p.HW;
     const int ntaps = p.Rt * p.St + (p.Cin == 4 ? 1 : 0);
-    int b = ((npix * p.LD + 3) & ~3) * 4 + ntaps * (p.CK / 4) * ((p.nt * 32) << p.lwn) * 16;   // halo image + weight tile
+    const int halo_pad = (npix * (p.LD / 4) + 255) & ~255;
+    const int b_pad = (ntaps * (p.CK / 4) * ((p.nt * 32) << p.lwn) + 255) & ~255;
+    int b = (halo_pad + b_pad) * 16 * (p.dma ? 2 : 1);   // halo image + weight tile (two buffers for the DMA pipeline)
     return b < 8192 ? 8192 : b;
 }
 
@@ -492,6 +538,8 @@ int bpb_conv_igemm(const BpbConvProb* d_probs, const BpbConvProb* h_probs, int n
         BPB_REQUIRE(p.CK >= 4 && p.CK <= 32 && (p.CK & (p.CK - 1)) == 0 && p.Cin % p.CK == 0 && (p.Cin == 4 || p.CK >= 8),
                     "bpb_conv_igemm: bad channel chunk CK=%d for Cin=%d", p.CK, p.Cin);
         BPB_REQUIRE(p.LD >= p.CK && p.LD % 4 == 0, "bpb_conv_igemm: bad LDS pitch %d", p.LD);
+        BPB_REQUIRE(p.x_bytes > 0 && p.w_bytes > 0 && p.x_bytes < 0xFFFFFFF0u && p.w_bytes < 0xFFFFFFF0u,
+                    "bpb_conv_igemm: tensors addressed through a buffer descriptor must be < 4 GiB");
         BPB_REQUIRE((p.mt_r == 1 || p.mt_r == 2) && (p.lwn == 0 || p.lwn == 1), "bpb_conv_igemm: bad tile shape mt=%d lwn=%d", p.mt_r, p.lwn);
         BPB_REQUIRE((1 << (p.lTI + p.lTH + p.lTW)) == (4 >> p.lwn) * p.mt_r * 32, "bpb_conv_igemm: M tile / wave layout mismatch");
         BPB_REQUIRE(p.nt == 1 || p.nt == 2, "bpb_conv_igemm: nt=%d", p.nt);

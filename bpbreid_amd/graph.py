@@ -236,19 +236,32 @@ class Net:
         hw = (tw - 1) * sa + span_w + 1
         ntc = (32 * nt) << lwn
         ntaps_b = rt * st + (1 if cin == 4 else 0)
-        lds_bytes = lambda ck_, ld_: ((ti * hh * hw * ld_ + 3) // 4 * 4) * 4 + ntaps_b * (ck_ // 4) * ntc * 16
+        pad256 = lambda v_: (v_ + 255) // 256 * 256
+
+        def lds_bytes(ck_, ld_, nbuf):
+            return (pad256(ti * hh * hw * (ld_ // 4)) + pad256(ntaps_b * (ck_ // 4) * ntc)) * 16 * nbuf
+        # Channel chunk CK: prefer the double-buffered DMA pipeline with two workgroups per CU (2 images <= 78 KB each
+        # workgroup), then DMA with one workgroup per CU, then synchronous staging.
         if cin == 4:
-            ck, ld = 4, 4
+            cks = [4]
         else:
-            ck = 32
-            while cin % ck:
-                ck //= 2
-            assert ck >= 8, 'Cin must be 4 or a multiple of 8'
-            # halo image + weight tile of one channel chunk: keep two workgroups resident per CU (160 KiB LDS)
-            while ck > 8 and lds_bytes(ck, ck + 4) > 78 * 1024:
-                ck //= 2
-            ld = ck + 4
-        assert lds_bytes(ck, ld) <= 160 * 1024, 'conv tile (halo + weights) exceeds LDS'
+            cks = [c_ for c_ in (32, 16, 8) if cin % c_ == 0]
+            assert cks, 'Cin must be 4 or a multiple of 8'
+        ld_of = lambda c_: 4 if cin == 4 else c_ + 4
+        dma = 1 if getattr(self, 'use_dma', True) else 0
+        choice = None
+        if dma:
+            for limit in (78 * 1024, 160 * 1024):
+                fit = [c_ for c_ in cks if lds_bytes(c_, ld_of(c_), 2) <= limit]
+                if fit:
+                    choice = (fit[0], 1)
+                    break
+        if choice is None:
+            fit = [c_ for c_ in cks if lds_bytes(c_, ld_of(c_), 1) <= 78 * 1024] or [c_ for c_ in cks if lds_bytes(c_, ld_of(c_), 1) <= 160 * 1024]
+            assert fit, 'conv tile (halo + weights) exceeds LDS'
+            choice = (fit[0], 0)
+        ck, dma = choice
+        ld = ld_of(ck)
         p = ConvProb()
         p.x, p.w, p.y = x_buf.data_ptr(), w_packed.data_ptr(), y_buf.data_ptr()
         p.bias = bias.data_ptr() if bias is not None else None
@@ -268,6 +281,10 @@ class Net:
         p.blk_begin = 0
         p.accumulate = accumulate
         p.mt_r, p.lwn, p.nt = mt_r, lwn, nt
+        p.dma = dma
+        p.x_bytes = x_buf.numel() * 4
+        p.w_bytes = w_packed.numel() * 4
+        p.magic_spp = magic(ld // 4)
         p.magic_hw, p.magic_hh = magic(hw), magic(hh)
         if stats is not None:
             st_buf = torch.empty(p.n_mtiles * 2 * cout, device=self.device, dtype=torch.float64)

@@ -57,6 +57,9 @@ typedef struct BpbConvProb {
     int tiles_a, tiles_b, n_mtiles, n_ntiles;
     int blk_begin;          // first blockIdx of this problem inside a grouped launch
     int accumulate;         // y += result
+    int dma;                // 1: double-buffered buffer_load..lds pipeline, 0: synchronous staging
+    unsigned x_bytes, w_bytes;   // sizes of the x and packed-w allocations (buffer descriptors: out-of-range reads return 0)
+    unsigned magic_spp;     // ceil(2^32 / (LD/4))
     int mt_r, lwn, nt;      // wave tile: mt_r 32-pixel sub-tiles (1|2), 2^lwn waves along channels (lwn 0|1), nt 32-channel sub-tiles (1|2)
     unsigned magic_hw, magic_hh;   // ceil(2^32/d) for d = HW, HH (staging index split without idiv)
 } BpbConvProb;
