@@ -41,6 +41,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=16)
+    ap.add_argument('--graph', type=int, default=1, help='1: replay the step from a hipGraph (falls back to eager launches if capture fails)')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -170,15 +171,29 @@ def main():
                                mask_filtering_training=True, distributed=world > 1)
     imgs, masks, pids = Cm.synth_batch(args.batch, args.height, args.width, args.parts, args.classes, seed=1234 + rank)
     data = {'image': imgs.to(dev), 'mask': masks.to(dev), 'pid': pids.to(dev)}      # resident in HBM before timing
+    step = lambda: eng.forward_backward(data)
+    mode = 'eager'
     for _ in range(args.warmup):
-        loss, _ = eng.forward_backward(data)
+        loss, _ = step()
     torch.cuda.synchronize()
+    if args.graph and world == 1:
+        try:
+            replay = eng.capture_step(data, warmup=1)
+            step = lambda: replay()
+            loss, _ = step()
+            torch.cuda.synchronize()
+            mode = 'hipgraph'
+        except Exception as ex:                        # capture is an optimisation; never fail the benchmark on it
+            sys.stderr.write('hipGraph capture failed, using eager launches: %r\n' % (ex,))
+            step = lambda: eng.forward_backward(data)
+            loss, _ = step()
+            torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, _ = eng.forward_backward(data)
+        loss, _ = step()
     host_enqueue = time.perf_counter() - t0         # host time to enqueue all steps (no sync inside the loop)
     torch.cuda.synchronize()
     if world > 1:
@@ -198,7 +213,7 @@ def main():
                                'visibility masks, fwd+loss+bwd+all-reduce+Adam (BASELINE configs[2]/[3])'
                                % (args.backbone, args.parts, args.height, args.width, args.batch, args.batch * world),
                    'parallelism': 'dp%d' % world, 'global_batch': args.batch * world, 'final_loss': final_loss,
-                   'host_enqueue_ms_per_step': 1e3 * host_enqueue / args.steps},
+                   'host_enqueue_ms_per_step': 1e3 * host_enqueue / args.steps, 'launch_mode': mode},
     }
     if rank == 0 and world == 1 and not args.no_roofline:
         plan = next(iter(model._plans.values()))
