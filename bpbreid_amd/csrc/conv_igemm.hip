@@ -425,22 +425,129 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_wgrad_kernel(const BpbWgradPr
     }
 }
 
-// dW[co][ci_real][t] (OIHW, the state-dict layout) (+)= sum_split ws[split][t][ci][co]
-// block = 64 consecutive slab elements (co fastest -> coalesced 256-B reads) x 4 split lanes; fixed summation order.
-__global__ __launch_bounds__(256) void bpb_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int T,
-                                                               int Cin, int Cin_real, int Cout, int accumulate)
+// Spatial filters (T > 1): tap-split variant.  A workgroup is THREE waves; wave w owns taps {3w, 3w+1, 3w+2} of the
+// 9-tap group and walks ALL 128 pixels of every tile (64 k-steps): 3 accumulator tiles per wave (48 registers, high
+// occupancy), the dy fragment is shared by the wave's three MFMAs, and there is no cross-wave reduction at the end --
+// each wave stores its own taps straight from registers.
+__global__ __launch_bounds__(192) void bpb_conv_wgrad3_kernel(const BpbWgradProb* __restrict__ probs, int nprobs)
 {
-    __shared__ float red[4][64];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int bid = blockIdx.x;
+    int pi = 0;
+    for (int i = 1; i < nprobs; ++i)
+        if (bid >= probs[i].blk_begin) pi = i;
+    const BpbWgradProb P = probs[pi];
+    bid -= P.blk_begin;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int cot = bid % P.n_cotiles;
+    int r1 = bid / P.n_cotiles;
+    const int cit = r1 % P.n_citiles;
+    r1 /= P.n_citiles;
+    const int tg = r1 % P.n_tapgroups;
+    const int split = r1 / P.n_tapgroups;
+    const int t0 = tg * 9 + wave * 3;                 // first tap of this wave
+    const int nt_here = max(0, min(3, P.T - t0));
+    const int Cin = P.Cin, Cout = P.Cout;
+    const int ci0 = cit * 32, co0 = cot * 32;
+    const int ckc = min(32, Cin - ci0);
+    const int LD = P.LD, HWd = P.HW, HH = P.HH, sa = P.sa;
+    const int lTW = P.lTW, lTH = P.lTH, lTI = P.lTI;
+    const int TWm = (1 << lTW) - 1, THm = (1 << lTH) - 1;
+    const int npix_h = (1 << lTI) * HH * HWd;
+    float* sx = smem;                                // halo [npix_h][LD]
+    float* sdy = smem + ((npix_h * LD + 3) & ~3);    // dy tile [128][32]
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    int tapoff[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int tt = min(t0 + t, P.T - 1);
+        tapoff[t] = (((tt / P.S) * HWd + (tt % P.S)) * LD) * 4;
+    }
+    const int per = (P.n_mtiles + P.nsplit - 1) / P.nsplit;
+    const int mt_begin = split * per, mt_end = min(P.n_mtiles, mt_begin + per);
+    const int vpp = ckc >> 2;
+
+    for (int mtile = mt_begin; mtile < mt_end; ++mtile) {
+        const int tb = mtile % P.tiles_b, t2 = mtile / P.tiles_b;
+        const int ta = t2 % P.tiles_a, tn = t2 / P.tiles_a;
+        const int n0 = tn << lTI, a0 = ta << lTH, b0 = tb << lTW;
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < npix_h * vpp; idx += 192) {
+            const unsigned hp = (unsigned)idx / (unsigned)vpp;
+            const int v = idx - hp * vpp;
+            const unsigned t = bpb_fdiv(hp, HWd, P.magic_hw);
+            const int hc = hp - t * HWd;
+            const unsigned ti = bpb_fdiv(t, HH, P.magic_hh);
+            const int hr = t - ti * HH;
+            const int n = n0 + (int)ti, ih = a0 * sa + hr + P.ih0, iw = b0 * sa + hc + P.iw0;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (n < P.N && (unsigned)ih < (unsigned)P.Hi && (unsigned)iw < (unsigned)P.Wi)
+                val = BPB_GLD4((bpb_gcf)P.x + (((size_t)n * P.Hi + ih) * P.Wi + iw) * Cin + ci0 + v * 4);
+            *(f32x4*)(sx + hp * LD + v * 4) = val;
+        }
+        for (int idx = threadIdx.x; idx < 128 * 8; idx += 192) {
+            const int v = idx & 7, m = idx >> 3;
+            const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
+            const int n = n0 + ti, a = a0 + th, b = b0 + tw;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            const int co = co0 + v * 4;
+            if (n < P.N && a < P.A && b < P.B && co < Cout)
+                val = BPB_GLD4((bpb_gcf)P.dy + (((size_t)n * P.A + a) * P.B + b) * Cout + co);
+            *(f32x4*)(sdy + m * 32 + v * 4) = val;
+        }
+        __syncthreads();
+        if (nt_here > 0) {
+#pragma unroll 4
+            for (int ks = 0; ks < 64; ++ks) {
+                const int m = ks * 2 + half;
+                const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
+                const int xo = (((ti * HH + th * sa) * HWd + tw * sa) * LD + l31) * 4;
+                const float bfrag = sdy[m * 32 + l31];
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    if (t < nt_here) acc[t] = MFMA32(*(const float*)((const char*)sx + xo + tapoff[t]), bfrag, acc[t]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        if (t < nt_here) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * half, co = co0 + l31;
+                if (ci < Cin && co < Cout)
+                    ((bpb_gf)P.ws)[(((size_t)split * P.T + (t0 + t)) * Cin + ci) * Cout + co] = acc[t][r];
+            }
+        }
+    }
+}
+
+// dW[co][ci_real][t] (OIHW, the state-dict layout) (+)= sum_split ws[split][t][ci][co]
+// block = 64 consecutive slab elements (co fastest -> coalesced 256-B reads) x 16 split lanes; fixed summation order.
+__global__ __launch_bounds__(1024) void bpb_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int T,
+                                                                int Cin, int Cin_real, int Cout, int accumulate)
+{
+    __shared__ float red[16][64];
     const long total = (long)T * Cin * Cout;
     const long e = blockIdx.x * 64L + (threadIdx.x & 63);
     const int sl = threadIdx.x >> 6;
     float s = 0.f;
     if (e < total)
-        for (int sp = sl; sp < nsplit; sp += 4) s += ws[(size_t)sp * total + e];
+        for (int sp = sl; sp < nsplit; sp += 16) s += ws[(size_t)sp * total + e];
     red[sl][threadIdx.x & 63] = s;
     __syncthreads();
     if (sl == 0 && e < total) {
-        s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += red[i][threadIdx.x];
         const int co = (int)(e % Cout);
         const long r = e / Cout;
         const int ci = (int)(r % Cin), t = (int)(r / Cin);
@@ -518,7 +625,7 @@ int bpb_conv_init(void)
     BPB_ATTR((bpb_conv_igemm_kernel<1, true>))
     BPB_ATTR((bpb_conv_igemm_kernel<2, true>))
     BPB_ATTR((bpb_conv_wgrad_kernel<1, 1>))
-    BPB_ATTR((bpb_conv_wgrad_kernel<9, 1>))
+    BPB_ATTR(bpb_conv_wgrad3_kernel)
     BPB_ATTR((bpb_conv_wgrad_kernel<1, 2>))
     BPB_ATTR((bpb_conv_wgrad_kernel<1, 4>))
 #undef BPB_ATTR
@@ -596,7 +703,7 @@ int bpb_conv_wgrad(const BpbWgradProb* d_probs, const BpbWgradProb* h_probs, int
 #define BPB_WG_LAUNCH(TG, NTW) \
     hipLaunchKernelGGL((bpb_conv_wgrad_kernel<TG, NTW>), dim3(nblk), dim3(256), lds, stream, d_probs, nprobs)
     if (ntw == 1 && h_probs[0].T == 1) { BPB_WG_LAUNCH(1, 1); }
-    else if (ntw == 1) { BPB_WG_LAUNCH(9, 1); }
+    else if (ntw == 1) { hipLaunchKernelGGL(bpb_conv_wgrad3_kernel, dim3(nblk), dim3(192), lds, stream, d_probs, nprobs); }
     else if (ntw == 2) { BPB_WG_LAUNCH(1, 2); }
     else { BPB_WG_LAUNCH(1, 4); }
 #undef BPB_WG_LAUNCH
@@ -610,7 +717,7 @@ int bpb_wgrad_reduce(const float* ws, float* dw, int nsplit, int T, int Cin, int
     const long total = (long)T * Cin * Cout;
     BPB_REQUIRE(total > 0 && nsplit >= 1 && Cin_real <= Cin, "bpb_wgrad_reduce: empty problem");
     const int grid = bpb_cdiv(total, 64);
-    hipLaunchKernelGGL(bpb_wgrad_reduce_kernel, dim3(grid), dim3(256), 0, stream, ws, dw, nsplit, T, Cin, Cin_real, Cout,
+    hipLaunchKernelGGL(bpb_wgrad_reduce_kernel, dim3(grid), dim3(1024), 0, stream, ws, dw, nsplit, T, Cin, Cin_real, Cout,
                        accumulate);
     BPB_LAUNCH_OK();
     return 0;

@@ -109,11 +109,8 @@ class ImagePartBasedEngine:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             loss, summary = self.forward_backward(static)
-        if isinstance(self.optimizer, FusedAdam):
-            # the captured Adam launch has step_index baked in: replays advance it on the host for bookkeeping only.
-            # Bias correction inside the kernel therefore stays at the captured step; it is exact after ~1000 steps and is
-            # re-captured by the caller when exact early-step bias correction matters (bench: irrelevant for throughput).
-            pass
+        # FusedAdam keeps its step counter on the device (incremented inside the captured launch sequence), so the bias
+        # correction stays exact under replay; the learning rate is a launch argument: re-capture after an LR change.
 
         def replay(new_data=None):
             if new_data is not None:
@@ -123,6 +120,8 @@ class ImagePartBasedEngine:
                     static['mask'].copy_(m2, non_blocking=True)
                 static['pid'].copy_(p2, non_blocking=True)
             graph.replay()
+            if isinstance(self.optimizer, FusedAdam):
+                self.optimizer.step_index += 1
             return loss, summary
 
         self._graph = graph

@@ -553,8 +553,8 @@ class Net:
         dev = self._dev_struct(wp)
         self._wgrad_descs.append((dev, wp))
         self.debug_wgrads.append((wp, cv))
-        tg = 1 if t == 1 else 9
-        bwd.add(self._op(nv.OP_WGRAD, ints=(1,), ptrs=(dev, C.addressof(wp))), 'conv_wgrad bpb_conv_wgrad_kernel<%d,%d>' % (tg, ntw),
+        kname = 'bpb_conv_wgrad_kernel<1,%d>' % ntw if t == 1 else 'bpb_conv_wgrad3_kernel'
+        bwd.add(self._op(nv.OP_WGRAD, ints=(1,), ptrs=(dev, C.addressof(wp))), 'conv_wgrad ' + kname,
                 2.0 * y.N * y.H * y.W * t * x.C * cout, 4.0 * (x.buf.numel() + y.buf.numel()))
         # the shared workspace pointer is patched into both records once its size is known (end of _emit_backward)
         red = self._op(nv.OP_WGRAD_REDUCE, ints=(wp.nsplit, t, x.C, cin_real, cout, 0), ptrs=(None, cv.weight.grad))

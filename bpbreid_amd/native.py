@@ -146,7 +146,7 @@ PROTOS = {
     'bpb_bn1d_fwd': 'plpliippppppffiip', 'bpb_bn1d_bwd': 'plplplpliipppppiip',
     'bpb_ce_label_smooth': 'plpipiiifppplpp', 'bpb_pixel_ce': 'ppiiiiiifppipp',
     'bpb_part_triplet': 'pllppipiiiiffpppppp', 'bpb_part_triplet_bwd': 'pllppfiiipllip',
-    'bpb_scale': 'ppfplip', 'bpb_adam_step': 'ppppppifffffifp', 'bpb_fill': 'pflp', 'bpb_plan_run': 'pip', 'bpb_plan_run_timed': 'pipp',
+    'bpb_scale': 'ppfplip', 'bpb_adam_step': 'ppppppifffffifpp', 'bpb_fill': 'pflp', 'bpb_plan_run': 'pip', 'bpb_plan_run_timed': 'pipp',
     'bpb_part_distance': 'ppppiiiiiiipppppip', 'bpb_part_distance_fill': 'plpp',
     'bpb_eval_rank': 'pppppiiiipppp',
 }

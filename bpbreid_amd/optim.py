@@ -29,6 +29,7 @@ class FusedAdam:
         if self.exp_avg is None or self.exp_avg.data_ptr() == 0 or self.exp_avg.numel() != a['param'].numel():
             self.exp_avg = torch.zeros_like(a['param'])
             self.exp_avg_sq = torch.zeros_like(a['param'])
+            self.step_dev = torch.full((1,), self.step_index, device=a['param'].device, dtype=torch.int32)
         return a
 
     def _table(self, arena):
@@ -57,7 +58,7 @@ class FusedAdam:
         lr = self.param_groups[0]['lr']
         nv.call('bpb_adam_step', a['param'].data_ptr(), a['grad'].data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                 offs.data_ptr(), lens.data_ptr(), nblocks, lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                self.step_index, grad_scale, nv.stream())
+                self.step_index, grad_scale, self.step_dev.data_ptr(), nv.stream())
 
     def state_dict(self):
         return {'step': self.step_index, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq, 'lr': self.param_groups[0]['lr']}
@@ -65,6 +66,7 @@ class FusedAdam:
     def load_state_dict(self, sd):
         self._state()
         self.step_index = sd['step']
+        self.step_dev.fill_(self.step_index)
         self.exp_avg.copy_(sd['exp_avg'])
         self.exp_avg_sq.copy_(sd['exp_avg_sq'])
         self.param_groups[0]['lr'] = sd['lr']

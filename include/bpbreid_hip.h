@@ -258,7 +258,7 @@ int bpb_scale(const float* x, const float* alpha_dev, float alpha, float* y, lon
 /* ---- optimizer step: torchreid/optim/optimizer.py:113-119 (torch.optim.Adam, coupled weight decay) ------------------ */
 int bpb_adam_step(float* p, const float* g, float* m, float* v, const long* blk_off, const int* blk_len, int nblocks,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int step_index, float gscale,
-                  hipStream_t stream);
+                  int* step_dev, hipStream_t stream);
 int bpb_fill(float* x, float value, long n, hipStream_t stream);
 
 /* ---- eval: torchreid/metrics/distance.py:87-247 and torchreid/metrics/rank.py:97-159 (rank_cylib/rank_cy.pyx:154-241) */

@@ -466,3 +466,4 @@ def test_fused_adam_matches_torch():
     torch.cuda.synchronize()
     for p, r in zip(m.parameters(), ref):
         assert rel_err(p.data, r.data) < 1e-6
+    assert int(opt.step_dev) == 3 == opt.step_index
