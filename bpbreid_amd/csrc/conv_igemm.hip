@@ -324,8 +324,13 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_wgrad_kernel(const BpbWgradPr
     const int TWm = (1 << lTW) - 1, THm = (1 << lTH) - 1;
     const int npix_h = (1 << lTI) * HH * HWd;
     constexpr int LDY = 32 * NTW;
-    float* sx = smem;                                // halo [npix_h][LD]
-    float* sdy = smem + ((npix_h * LD + 3) & ~3);    // dy tile [128][LDY]
+    // LDS image of one pixel tile (16-byte slots): halo [halo pixel][LD/4] then dy [128][LDY/4]; regions padded to 256 slots.
+    const int spp = LD >> 2;
+    const int halo_slots = npix_h * spp;
+    const int halo_pad = (halo_slots + 255) & ~255;
+    constexpr int dy_slots = 128 * (LDY / 4);
+    const int bufbytes = (halo_pad + dy_slots) * 16;
+    const bool dma = P.dma != 0;
 
     f32x16 acc[TG][NTW];
 #pragma unroll
@@ -345,38 +350,80 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_wgrad_kernel(const BpbWgradPr
     // M-tile range of this split
     const int per = (P.n_mtiles + P.nsplit - 1) / P.nsplit;
     const int mt_begin = split * per, mt_end = min(P.n_mtiles, mt_begin + per);
-    const int vpp = ckc >> 2;   // float4 per halo pixel.  When ckc < 32 the A fragment of lanes >= ckc reads past the row
-                                // (other pixels / the dy tile): those MFMA rows are never stored, rows are independent.
+    const int vpp = ckc >> 2;   // data slots per halo pixel.  When ckc < 32 the A fragment of lanes >= ckc reads past the row
+                                // (pad / other pixels): those MFMA rows are never stored, rows are independent.
 
-    for (int mtile = mt_begin; mtile < mt_end; ++mtile) {
+    auto tile_origin = [&](int mtile, int& n0, int& a0, int& b0) {
         const int tb = mtile % P.tiles_b, t2 = mtile / P.tiles_b;
         const int ta = t2 % P.tiles_a, tn = t2 / P.tiles_a;
-        const int n0 = tn << lTI, a0 = ta << lTH, b0 = tb << lTW;
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < npix_h * vpp; idx += 256) {
-            const unsigned hp = (unsigned)idx / (unsigned)vpp;
-            const int v = idx - hp * vpp;
-            const unsigned t = bpb_fdiv(hp, HWd, P.magic_hw);
-            const int hc = hp - t * HWd;
-            const unsigned ti = bpb_fdiv(t, HH, P.magic_hh);
-            const int hr = t - ti * HH;
-            const int n = n0 + (int)ti, ih = a0 * sa + hr + P.ih0, iw = b0 * sa + hc + P.iw0;
+        n0 = tn << lTI; a0 = ta << lTH; b0 = tb << lTW;
+    };
+    auto halo_voff = [&](int idx, int n0, int a0, int b0) -> unsigned {
+        const unsigned hp = bpb_fdiv((unsigned)idx, spp, P.magic_spp);
+        const int v = idx - hp * spp;
+        if (idx >= halo_slots || v >= vpp) return 0xFFFFFFF0u;
+        const unsigned t = bpb_fdiv(hp, HWd, P.magic_hw);
+        const int hc = hp - t * HWd;
+        const unsigned ti = bpb_fdiv(t, HH, P.magic_hh);
+        const int hr = t - ti * HH;
+        const int n = n0 + (int)ti, ih = a0 * sa + hr + P.ih0, iw = b0 * sa + hc + P.iw0;
+        if (n < P.N && (unsigned)ih < (unsigned)P.Hi && (unsigned)iw < (unsigned)P.Wi)
+            return ((((unsigned)n * P.Hi + ih) * P.Wi + iw) * Cin + ci0 + v * 4) * 4u;
+        return 0xFFFFFFF0u;
+    };
+    auto dy_voff = [&](int idx, int n0, int a0, int b0) -> unsigned {
+        const int v = idx % (LDY / 4), m = idx / (LDY / 4);
+        const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
+        const int n = n0 + ti, a = a0 + th, b = b0 + tw;
+        const int co = co0 + v * 4;
+        if (n < P.N && a < P.A && b < P.B && co < Cout)   // Cout % 4 == 0
+            return ((((unsigned)n * P.A + a) * P.B + b) * Cout + co) * 4u;
+        return 0xFFFFFFF0u;
+    };
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)P.x, 0, (int)P.x_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)P.dy, 0, (int)P.dy_bytes, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    auto dma_issue = [&](int mtile, int buf) {
+        int n0, a0, b0;
+        tile_origin(mtile, n0, a0, b0);
+        char* base = (char*)smem + buf * bufbytes + wave * 1024;
+        for (int s0 = 0; s0 < halo_pad; s0 += 256)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(base + s0 * 16), 16,
+                                                     (int)halo_voff(s0 + (int)threadIdx.x, n0, a0, b0), 0, 0, 0);
+        for (int s0 = 0; s0 < dy_slots; s0 += 256)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lds_ptr_t)(base + (halo_pad + s0) * 16), 16,
+                                                     (int)dy_voff(s0 + (int)threadIdx.x, n0, a0, b0), 0, 0, 0);
+    };
+    auto sync_stage = [&](int mtile) {
+        int n0, a0, b0;
+        tile_origin(mtile, n0, a0, b0);
+        for (int idx = threadIdx.x; idx < halo_pad; idx += 256) {
+            const unsigned vo = halo_voff(idx, n0, a0, b0);
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (n < P.N && (unsigned)ih < (unsigned)P.Hi && (unsigned)iw < (unsigned)P.Wi)
-                val = BPB_GLD4((bpb_gcf)P.x + (((size_t)n * P.Hi + ih) * P.Wi + iw) * Cin + ci0 + v * 4);
-            *(f32x4*)(sx + hp * LD + v * 4) = val;
+            if (vo != 0xFFFFFFF0u) val = BPB_GLD4((const char BPB_GLOBAL*)P.x + vo);
+            *(f32x4*)((char*)smem + idx * 16) = val;
         }
-        for (int idx = threadIdx.x; idx < 128 * (LDY / 4); idx += 256) {
-            const int v = idx % (LDY / 4), m = idx / (LDY / 4);
-            const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
-            const int n = n0 + ti, a = a0 + th, b = b0 + tw;
+        for (int idx = threadIdx.x; idx < dy_slots; idx += 256) {
+            const unsigned vo = dy_voff(idx, n0, a0, b0);
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            const int co = co0 + v * 4;
-            if (n < P.N && a < P.A && b < P.B && co < Cout)   // Cout % 4 == 0
-                val = BPB_GLD4((bpb_gcf)P.dy + (((size_t)n * P.A + a) * P.B + b) * Cout + co);
-            *(f32x4*)(sdy + m * LDY + v * 4) = val;
+            if (vo != 0xFFFFFFF0u) val = BPB_GLD4((const char BPB_GLOBAL*)P.dy + vo);
+            *(f32x4*)((char*)smem + (halo_pad + idx) * 16) = val;
         }
-        __syncthreads();
+    };
+
+    if (dma && mt_begin < mt_end) dma_issue(mt_begin, 0);
+    for (int mtile = mt_begin; mtile < mt_end; ++mtile) {
+        __syncthreads();   // dma: this tile has landed (barrier drains vmcnt) and the other buffer is free
+        int bufoff = 0;
+        if (dma) {
+            bufoff = ((mtile - mt_begin) & 1) * bufbytes;
+            if (mtile + 1 < mt_end) dma_issue(mtile + 1, (mtile + 1 - mt_begin) & 1);
+        } else {
+            sync_stage(mtile);
+            __syncthreads();
+        }
+        const char* sx = (const char*)smem + bufoff;
+        const float* sdy = (const float*)(sx + halo_pad * 16);
         // wave handles pixels [wave*32, wave*32+32): 16 k-steps of 2 pixels
 #pragma unroll 4
         for (int ks = 0; ks < 16; ++ks) {
@@ -389,13 +436,14 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_wgrad_kernel(const BpbWgradPr
 #pragma unroll
             for (int t = 0; t < TG; ++t) {
                 if (t < nt_here) {
-                    const float afrag = *(const float*)((const char*)sx + xo + tapoff[t]);
+                    const float afrag = *(const float*)(sx + xo + tapoff[t]);
 #pragma unroll
                     for (int nt = 0; nt < NTW; ++nt) acc[t][nt] = MFMA32(afrag, bfrag[nt], acc[t][nt]);
                 }
             }
         }
     }
+    __syncthreads();
 
     // cross-wave reduction through LDS, one tap at a time; row = ci, col = co
     float* red = smem;   // [4 waves][16 regs][64 lanes]
@@ -420,111 +468,6 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_wgrad_kernel(const BpbWgradPr
                     if (ci < Cin && co < Cout)
                         ((bpb_gf)P.ws)[(((size_t)split * P.T + (t0 + t)) * Cin + ci) * Cout + co] = s;
                 }
-            }
-        }
-    }
-}
-
-// Spatial filters (T > 1): tap-split variant.  A workgroup is THREE waves; wave w owns taps {3w, 3w+1, 3w+2} of the
-// 9-tap group and walks ALL 128 pixels of every tile (64 k-steps): 3 accumulator tiles per wave (48 registers, high
-// occupancy), the dy fragment is shared by the wave's three MFMAs, and there is no cross-wave reduction at the end --
-// each wave stores its own taps straight from registers.
-__global__ __launch_bounds__(192) void bpb_conv_wgrad3_kernel(const BpbWgradProb* __restrict__ probs, int nprobs)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    int bid = blockIdx.x;
-    int pi = 0;
-    for (int i = 1; i < nprobs; ++i)
-        if (bid >= probs[i].blk_begin) pi = i;
-    const BpbWgradProb P = probs[pi];
-    bid -= P.blk_begin;
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int half = lane >> 5, l31 = lane & 31;
-    const int cot = bid % P.n_cotiles;
-    int r1 = bid / P.n_cotiles;
-    const int cit = r1 % P.n_citiles;
-    r1 /= P.n_citiles;
-    const int tg = r1 % P.n_tapgroups;
-    const int split = r1 / P.n_tapgroups;
-    const int t0 = tg * 9 + wave * 3;                 // first tap of this wave
-    const int nt_here = max(0, min(3, P.T - t0));
-    const int Cin = P.Cin, Cout = P.Cout;
-    const int ci0 = cit * 32, co0 = cot * 32;
-    const int ckc = min(32, Cin - ci0);
-    const int LD = P.LD, HWd = P.HW, HH = P.HH, sa = P.sa;
-    const int lTW = P.lTW, lTH = P.lTH, lTI = P.lTI;
-    const int TWm = (1 << lTW) - 1, THm = (1 << lTH) - 1;
-    const int npix_h = (1 << lTI) * HH * HWd;
-    float* sx = smem;                                // halo [npix_h][LD]
-    float* sdy = smem + ((npix_h * LD + 3) & ~3);    // dy tile [128][32]
-
-    f32x16 acc[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    int tapoff[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        const int tt = min(t0 + t, P.T - 1);
-        tapoff[t] = (((tt / P.S) * HWd + (tt % P.S)) * LD) * 4;
-    }
-    const int per = (P.n_mtiles + P.nsplit - 1) / P.nsplit;
-    const int mt_begin = split * per, mt_end = min(P.n_mtiles, mt_begin + per);
-    const int vpp = ckc >> 2;
-
-    for (int mtile = mt_begin; mtile < mt_end; ++mtile) {
-        const int tb = mtile % P.tiles_b, t2 = mtile / P.tiles_b;
-        const int ta = t2 % P.tiles_a, tn = t2 / P.tiles_a;
-        const int n0 = tn << lTI, a0 = ta << lTH, b0 = tb << lTW;
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < npix_h * vpp; idx += 192) {
-            const unsigned hp = (unsigned)idx / (unsigned)vpp;
-            const int v = idx - hp * vpp;
-            const unsigned t = bpb_fdiv(hp, HWd, P.magic_hw);
-            const int hc = hp - t * HWd;
-            const unsigned ti = bpb_fdiv(t, HH, P.magic_hh);
-            const int hr = t - ti * HH;
-            const int n = n0 + (int)ti, ih = a0 * sa + hr + P.ih0, iw = b0 * sa + hc + P.iw0;
-            f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (n < P.N && (unsigned)ih < (unsigned)P.Hi && (unsigned)iw < (unsigned)P.Wi)
-                val = BPB_GLD4((bpb_gcf)P.x + (((size_t)n * P.Hi + ih) * P.Wi + iw) * Cin + ci0 + v * 4);
-            *(f32x4*)(sx + hp * LD + v * 4) = val;
-        }
-        for (int idx = threadIdx.x; idx < 128 * 8; idx += 192) {
-            const int v = idx & 7, m = idx >> 3;
-            const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
-            const int n = n0 + ti, a = a0 + th, b = b0 + tw;
-            f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            const int co = co0 + v * 4;
-            if (n < P.N && a < P.A && b < P.B && co < Cout)
-                val = BPB_GLD4((bpb_gcf)P.dy + (((size_t)n * P.A + a) * P.B + b) * Cout + co);
-            *(f32x4*)(sdy + m * 32 + v * 4) = val;
-        }
-        __syncthreads();
-        if (nt_here > 0) {
-#pragma unroll 4
-            for (int ks = 0; ks < 64; ++ks) {
-                const int m = ks * 2 + half;
-                const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
-                const int xo = (((ti * HH + th * sa) * HWd + tw * sa) * LD + l31) * 4;
-                const float bfrag = sdy[m * 32 + l31];
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
-                    if (t < nt_here) acc[t] = MFMA32(*(const float*)((const char*)sx + xo + tapoff[t]), bfrag, acc[t]);
-            }
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        if (t < nt_here) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * half, co = co0 + l31;
-                if (ci < Cin && co < Cout)
-                    ((bpb_gf)P.ws)[(((size_t)split * P.T + (t0 + t)) * Cin + ci) * Cout + co] = acc[t][r];
             }
         }
     }
@@ -625,7 +568,7 @@ int bpb_conv_init(void)
     BPB_ATTR((bpb_conv_igemm_kernel<1, true>))
     BPB_ATTR((bpb_conv_igemm_kernel<2, true>))
     BPB_ATTR((bpb_conv_wgrad_kernel<1, 1>))
-    BPB_ATTR(bpb_conv_wgrad3_kernel)
+    BPB_ATTR((bpb_conv_wgrad_kernel<9, 1>))
     BPB_ATTR((bpb_conv_wgrad_kernel<1, 2>))
     BPB_ATTR((bpb_conv_wgrad_kernel<1, 4>))
 #undef BPB_ATTR
@@ -694,8 +637,11 @@ int bpb_conv_wgrad(const BpbWgradProb* d_probs, const BpbWgradProb* h_probs, int
                     p.n_tapgroups == (p.T == 1 ? 1 : bpb_cdiv(p.T, 9)), "bpb_conv_wgrad: tile counts mismatch");
         nblk += p.nsplit * p.n_tapgroups * p.n_citiles * p.n_cotiles;
         const int npix = (1 << p.lTI) * p.HH * p.HW;
-        int l = ((npix * p.LD + 3) & ~3) * 4 + 128 * 32 * ntw * 4;
+        const int halo_pad = (npix * (p.LD / 4) + 255) & ~255;
+        int l = (halo_pad + 128 * 8 * ntw) * 16 * (p.dma ? 2 : 1);
         if (l < 16384) l = 16384;
+        BPB_REQUIRE(p.x_bytes > 0 && p.dy_bytes > 0 && p.x_bytes < 0xFFFFFFF0u && p.dy_bytes < 0xFFFFFFF0u,
+                    "bpb_conv_wgrad: tensors addressed through a buffer descriptor must be < 4 GiB");
         lds = l > lds ? l : lds;
     }
     BPB_REQUIRE(lds <= 160 * 1024, "bpb_conv_wgrad: needs %d B of LDS", lds);
@@ -703,7 +649,7 @@ int bpb_conv_wgrad(const BpbWgradProb* d_probs, const BpbWgradProb* h_probs, int
 #define BPB_WG_LAUNCH(TG, NTW) \
     hipLaunchKernelGGL((bpb_conv_wgrad_kernel<TG, NTW>), dim3(nblk), dim3(256), lds, stream, d_probs, nprobs)
     if (ntw == 1 && h_probs[0].T == 1) { BPB_WG_LAUNCH(1, 1); }
-    else if (ntw == 1) { hipLaunchKernelGGL(bpb_conv_wgrad3_kernel, dim3(nblk), dim3(192), lds, stream, d_probs, nprobs); }
+    else if (ntw == 1) { BPB_WG_LAUNCH(9, 1); }
     else if (ntw == 2) { BPB_WG_LAUNCH(1, 2); }
     else { BPB_WG_LAUNCH(1, 4); }
 #undef BPB_WG_LAUNCH

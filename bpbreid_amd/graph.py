@@ -546,14 +546,18 @@ class Net:
         wp.nsplit = max(1, min(-(-wp.n_mtiles // 2), -(-512 // pairs)))
         wp.blk_begin = 0
         wp.magic_hw, wp.magic_hh = magic(wp.HW), magic(wp.HH)
-        lds = ((1 << wp.lTI) * wp.HH * wp.HW * wp.LD) * 4 + 128 * 32 * ntw * 4
-        assert lds <= 160 * 1024, 'wgrad tile exceeds LDS'
+        halo_pad = ((1 << wp.lTI) * wp.HH * wp.HW * (wp.LD // 4) + 255) // 256 * 256
+        lds1 = (halo_pad + 128 * 8 * ntw) * 16
+        assert lds1 <= 160 * 1024, 'wgrad tile exceeds LDS'
+        wp.dma = 1 if (getattr(self, 'use_dma', True) and 2 * lds1 <= 160 * 1024) else 0
+        wp.x_bytes, wp.dy_bytes = x.buf.numel() * 4, gy.numel() * 4
+        wp.magic_spp = magic(wp.LD // 4)
         elems = wp.nsplit * t * x.C * cout
         ws_requests.append((elems, wp, self._bwd_slot))
         dev = self._dev_struct(wp)
         self._wgrad_descs.append((dev, wp))
         self.debug_wgrads.append((wp, cv))
-        kname = 'bpb_conv_wgrad_kernel<1,%d>' % ntw if t == 1 else 'bpb_conv_wgrad3_kernel'
+        kname = 'bpb_conv_wgrad_kernel<%d,%d>' % (1 if t == 1 else 9, ntw)
         bwd.add(self._op(nv.OP_WGRAD, ints=(1,), ptrs=(dev, C.addressof(wp))), 'conv_wgrad ' + kname,
                 2.0 * y.N * y.H * y.W * t * x.C * cout, 4.0 * (x.buf.numel() + y.buf.numel()))
         # the shared workspace pointer is patched into both records once its size is known (end of _emit_backward)

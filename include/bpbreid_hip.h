@@ -78,6 +78,8 @@ typedef struct BpbWgradProb {
     int tiles_a, tiles_b, n_mtiles;
     int n_citiles, n_cotiles, n_tapgroups, nsplit;
     int blk_begin;
+    int dma;               // 1: double-buffered buffer_load..lds pipeline over the pixel tiles
+    unsigned x_bytes, dy_bytes, magic_spp;
     unsigned magic_hw, magic_hh;
 } BpbWgradProb;
 
