@@ -109,6 +109,23 @@ def cpu_baseline(args):
                       'reference PyTorch-CPU path' % (args.backbone, args.parts, args.height, args.width, n, args.batch)}
 
 
+def pmc_traffic(sym):
+    """HBM bytes per launch of kernel `sym` from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_pmc_hbm.json, written by tools/pmc_hbm.py: FETCH_SIZE and WRITE_SIZE collected in separate passes,
+    bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- the gfx950 half-count correction of MI355X_MICROARCH.md, HBM section).
+    Counters cannot be read from inside the process, so this is the profile's figure, not a live one; null if absent."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm.json')
+    norm = lambda s_: s_.replace('void ', '').split('(')[0].replace(' ', '')
+    try:
+        table = json.load(open(path))
+    except Exception:
+        return {'traffic': None}
+    row = table.get(norm(sym))
+    if not row:
+        return {'traffic': None}
+    return {'traffic': row['hbm_bytes_per_launch'], 'traffic_source': 'profiles/r01_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)'}
+
+
 def roofline(model, plan):
     """Live per-launch durations (HIP events on the launch stream) of one forward + backward of the backbone plan.
     Dominant kernel = the kernel symbol with the largest summed duration; achieved = its algorithmic FLOPs / its time."""
@@ -135,6 +152,8 @@ def roofline(model, plan):
         achieved = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
         r = {'bound': 'hbm', 'kernel': sym, 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
              'traffic': None}
+    r['algorithmic_bytes_per_launch'] = dom['bytes'] / dom['launches']
+    r.update(pmc_traffic(sym))
     r.update({'avg_launch_us': dom['ms'] * 1e3 / dom['launches'], 'launches_per_step': dom['launches'],
               'kernel_ms_per_step': dom['ms'], 'backbone_ms_fwd_bwd': total_ms,
               'all_conv_tflops': conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else None,

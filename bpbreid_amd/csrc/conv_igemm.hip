@@ -27,8 +27,8 @@ __device__ __forceinline__ unsigned bpb_fdiv(unsigned x, unsigned d, unsigned ma
     return d == 1 ? x : __umulhi(x, magic);
 }
 
-template <int NT, bool C4>
-__global__ __launch_bounds__(256) void bpb_conv_igemm_kernel(const BpbConvProb* __restrict__ probs, int nprobs)
+template <int NT, bool C4, int MTr>
+__global__ __launch_bounds__(256, 2) void bpb_conv_igemm_kernel(const BpbConvProb* __restrict__ probs, int nprobs)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int bid = blockIdx.x;
@@ -43,35 +43,34 @@ __global__ __launch_bounds__(256) void bpb_conv_igemm_kernel(const BpbConvProb* 
     const int half = lane >> 5, l31 = lane & 31;
     const int lTW = P.lTW, lTH = P.lTH, lTI = P.lTI;
     const int TWm = (1 << lTW) - 1, THm = (1 << lTH) - 1;
-    const int ntile = bid % P.n_ntiles, mtile = bid / P.n_ntiles;
-    const int tb = mtile % P.tiles_b, t2 = mtile / P.tiles_b;
-    const int ta = t2 % P.tiles_a, tn = t2 / P.tiles_a;
-    const int n0 = tn << lTI, a0 = ta << lTH, b0 = tb << lTW;
+    // One workgroup walks `tpb` consecutive M tiles of one N tile: the halo of tile i+1 streams into LDS while the MFMA loop
+    // of tile i runs and while its epilogue drains, so the load / compute / store phases of the workgroups on a CU no longer
+    // run in lock-step (with one tile per workgroup and every workgroup launched at once they do).
+    const int ntile = bid % P.n_ntiles, mgroup = bid / P.n_ntiles;
+    const int mt_first = mgroup * P.tpb, mt_last = min(P.n_mtiles, mt_first + P.tpb);
     const int LD = P.LD, HWd = P.HW, HH = P.HH, sa = P.sa;
     const int Cin = P.Cin, Cout = P.Cout, cin4 = Cin >> 2;
     const int Rt = P.Rt, St = P.St, ntaps = Rt * St;
-    const bpb_gcf gx = (bpb_gcf)P.x;
-    const bpb_gcf gw = (bpb_gcf)P.w;
     // Workgroup tile = (WM * MT * 32 pixels) x (WN * NT * 32 channels) with WM * WN = 4 waves.  MT in {1,2} and WN in {1,2}
     // are per-problem (runtime, wave-uniform): small tiles give the deep, low-resolution HRNet branches enough
     // workgroups to occupy 256 CUs (a 256-channel 8x4 map at batch 64 is only eight 256-pixel tiles).
-    const int MTr = P.mt_r, lwn = P.lwn;
+    const int lwn = P.lwn;                       // MTr (template) = P.mt_r
     const int wm = wave >> lwn, wni = wave & ((1 << lwn) - 1);
     const int NTC = (NT * 32) << lwn;            // output channels per workgroup
     const int lNTC = (NT == 1 ? 5 : 6) + lwn;
 
-    int pixoff[2];   // byte offset of this lane's pixel (per 32-pixel sub-tile) inside the halo tile
+    int pixoff[MTr];   // byte offset of this lane's pixel (per 32-pixel sub-tile) inside the halo tile
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int m = (wm * MTr + min(mt, MTr - 1)) * 32 + l31;
+    for (int mt = 0; mt < MTr; ++mt) {
+        const int m = (wm * MTr + mt) * 32 + l31;
         const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
         pixoff[mt] = (((ti * HH + th * sa) * HWd + tw * sa) * LD) * 4 + (C4 ? 0 : half * 16);
     }
     const int cout_l = ntile * NTC + wni * NT * 32 + l31;
 
-    f32x16 acc[2][NT];
+    f32x16 acc[MTr][NT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MTr; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -82,9 +81,12 @@ __global__ __launch_bounds__(256) void bpb_conv_igemm_kernel(const BpbConvProb* 
     const int npix = (1 << lTI) * HH * HWd;
     const int KG = C4 ? 1 : (CK >> 3);         // 8-channel k-groups per tap inside one chunk
     const int nj = C4 ? ((ntaps + 1) >> 1) : ntaps * KG;
-    // LDS image of one channel chunk ("slots" of 16 bytes):
-    //   halo   [halo pixel][spp slots]   spp = LD/4 = CK/4 data slots (+1 pad slot unless Cin == 4)
-    //   weight [tap][CK/4][NTC]          placed behind the halo region; both regions padded to 256 slots
+    const int nch = Cin / CK;                  // channel chunks per tile
+    // LDS map (16-byte "slots"):
+    //   halo image(s)  [halo pixel][spp]     spp = LD/4 = CK/4 data slots (+1 pad slot unless Cin == 4); 1 or 2 buffers
+    //   weight tile(s) [tap][CK/4][NTC]      wres: one tile per channel chunk, loaded once per workgroup (resident);
+    //                                        otherwise one per buffer, re-staged with every halo image
+    //   stats scratch  4 KiB                 (never a DMA target)
     // Both MFMA operands come from LDS (in-order ds_read returns -> counted lgkmcnt waits).
     const int qn = CK >> 2;
     const int spp = LD >> 2;
@@ -92,13 +94,15 @@ __global__ __launch_bounds__(256) void bpb_conv_igemm_kernel(const BpbConvProb* 
     const int halo_pad = (halo_slots + 255) & ~255;
     const int nB = (ntaps + (C4 ? 1 : 0)) * qn * NTC;   // (C4: one extra zero tap for the phantom half)
     const int b_pad = (nB + 255) & ~255;
-    const int bufbytes = (halo_pad + b_pad) * 16;
+    const bool dma = P.dma != 0, wres = P.wres != 0;
+    const int nbuf = dma ? 2 : 1;
+    const int wbase = nbuf * halo_pad * 16;                       // byte offset of the weight region
+    const int redbase = wbase + (wres ? nch : nbuf) * b_pad * 16; // byte offset of the stats scratch
     const int tapB = qn * NTC * 16;            // bytes per tap in the weight region
-    const int boff_lane = halo_pad * 16 + (C4 ? 0 : half * NTC * 16) + (wni * NT * 32 + l31) * 16;
-    const bool dma = P.dma != 0;
+    const int boff_lane = (C4 ? 0 : half * NTC * 16) + (wni * NT * 32 + l31) * 16;
 
     // byte offset of slot `idx` of chunk `cb` inside x / w; 0xFFFFFFF0 = "out of range" (buffer loads return 0 there)
-    auto halo_voff = [&](int idx, int cb) -> unsigned {
+    auto halo_voff = [&](int idx, int cb, int n0, int a0, int b0) -> unsigned {
         const unsigned hp = bpb_fdiv((unsigned)idx, spp, P.magic_spp);
         const int v = idx - hp * spp;
         if (idx >= halo_slots || v >= qn) return 0xFFFFFFF0u;
@@ -123,52 +127,191 @@ __global__ __launch_bounds__(256) void bpb_conv_igemm_kernel(const BpbConvProb* 
         return (((unsigned)(widx * cin4 + (cb >> 2) + q) * Cout + co) * 4) * 4u;
     };
     // (a) asynchronous path: buffer_load ... lds (global -> LDS DMA, no staging registers), double-buffered so that the
-    //     image of chunk c+1 streams in while the MFMA loop of chunk c runs.  One barrier per chunk.
+    //     image of work item i+1 (next channel chunk, or first chunk of the next tile) streams in while the MFMA loop of
+    //     item i runs.  One barrier per item.
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)P.x, 0, (int)P.x_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)P.w, 0, (int)P.w_bytes, 0x00020000);
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    auto dma_issue = [&](int cb, int buf) {
-        char* base = (char*)smem + buf * bufbytes + wave * 1024;     // wave-uniform; lanes land at +16*lane
-        for (int b0s = 0; b0s < halo_pad; b0s += 256)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(base + b0s * 16), 16,
-                                                     (int)halo_voff(b0s + (int)threadIdx.x, cb), 0, 0, 0);
+    auto dma_weights = [&](int cb, int slot) {
+        char* base = (char*)smem + wbase + slot * b_pad * 16 + wave * 1024;
         for (int b0s = 0; b0s < b_pad; b0s += 256)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(base + (halo_pad + b0s) * 16), 16,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(base + b0s * 16), 16,
                                                      (int)b_voff(b0s + (int)threadIdx.x, cb), 0, 0, 0);
     };
+    auto tile_origin = [&](int mtile, int& n0, int& a0, int& b0) {
+        const int tb = mtile % P.tiles_b, t2 = mtile / P.tiles_b;
+        const int ta = t2 % P.tiles_a, tn = t2 / P.tiles_a;
+        n0 = tn << lTI; a0 = ta << lTH; b0 = tb << lTW;
+    };
+    auto dma_issue = [&](int mtile, int cb, int buf) {
+        int n0, a0, b0;
+        tile_origin(mtile, n0, a0, b0);
+        char* base = (char*)smem + buf * halo_pad * 16 + wave * 1024;     // wave-uniform; lanes land at +16*lane
+        for (int b0s = 0; b0s < halo_pad; b0s += 256)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(base + b0s * 16), 16,
+                                                     (int)halo_voff(b0s + (int)threadIdx.x, cb, n0, a0, b0), 0, 0, 0);
+        if (!wres) dma_weights(cb, buf);
+    };
     // (b) synchronous path (fallback when the double-buffered image does not fit in LDS)
-    auto sync_stage = [&](int cb) {
-        for (int idx = threadIdx.x; idx < halo_pad; idx += 256) {
-            const unsigned vo = halo_voff(idx, cb);
-            f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (vo != 0xFFFFFFF0u) val = BPB_GLD4((const char BPB_GLOBAL*)P.x + vo);
-            *(f32x4*)((char*)smem + idx * 16) = val;
-        }
+    auto sync_weights = [&](int cb, int slot) {
         for (int bi = threadIdx.x; bi < b_pad; bi += 256) {
             const unsigned vo = b_voff(bi, cb);
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
             if (vo != 0xFFFFFFF0u) val = BPB_GLD4((const char BPB_GLOBAL*)P.w + vo);
-            *(f32x4*)((char*)smem + (halo_pad + bi) * 16) = val;
+            *(f32x4*)((char*)smem + wbase + (slot * b_pad + bi) * 16) = val;
+        }
+    };
+    auto sync_stage = [&](int mtile, int cb) {
+        int n0, a0, b0;
+        tile_origin(mtile, n0, a0, b0);
+        for (int idx = threadIdx.x; idx < halo_pad; idx += 256) {
+            const unsigned vo = halo_voff(idx, cb, n0, a0, b0);
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (vo != 0xFFFFFFF0u) val = BPB_GLD4((const char BPB_GLOBAL*)P.x + vo);
+            *(f32x4*)((char*)smem + idx * 16) = val;
+        }
+        if (!wres) sync_weights(cb, 0);
+    };
+
+    // ---- epilogue of one M tile: C/D layout of 32x32 MFMA: col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const __amdgpu_buffer_rsrc_t ry =
+        __builtin_amdgcn_make_buffer_rsrc((void*)P.y, 0, P.N * P.Ho * P.Wo * Cout * 4, 0x00020000);
+    const bpb_gcf gbias = (bpb_gcf)P.bias;
+    float bias_v[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bias_v[nt] = (gbias && cout_l + nt * 32 < Cout) ? gbias[cout_l + nt * 32] : 0.f;
+    const bool accum = P.accumulate != 0;
+    auto epilogue = [&](int mtile) {
+        int n0, a0, b0;
+        tile_origin(mtile, n0, a0, b0);
+        // opaque copy: keeps the per-row address arithmetic inside the work loop (hoisted, it costs ~100 VGPRs)
+        int hq = half;
+        asm volatile("" : "+v"(hq));
+        double ssum[NT], ssq[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            ssum[nt] = 0.0;
+            ssq[nt] = 0.0;
+        }
+        // Stores (and the loads of the accumulate mode) go through a buffer descriptor: an out-of-range offset is dropped
+        // by the hardware, so tile edges need no exec-mask branches.  Offsets are 32-bit; the output is <= 1 GiB (checked
+        // on the host), an invalid pixel contributes 0x80000000 and an invalid channel 0x40000000 to the offset, so every
+        // invalid combination lands beyond the descriptor's range without any select.
+        const unsigned PIX_OOB = 0x80000000u, CH_OOB = 0x40000000u;
+        const int pstride = P.osw * Cout * 4;
+        unsigned cofs[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) cofs[nt] = (cout_l + nt * 32 < Cout) ? (unsigned)(nt * 128) : CH_OOB;
+#pragma unroll
+        for (int mt = 0; mt < MTr; ++mt) {
+            unsigned offs[16];
+            if (lTW >= 2) {
+                // tile width >= 4: the four accumulator rows (r & 3) of a register quad are four consecutive pixels of one
+                // image row -> one address computation per quad, then constant strides
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int m = (wm * MTr + mt) * 32 + 8 * rq + 4 * hq;
+                    const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
+                    const int n = n0 + ti, a = a0 + th, b = b0 + tw;
+                    const bool pq = (n < P.N) && (a < P.A);
+                    const unsigned qoff = (unsigned)(((n * P.Ho + (a * P.osh + P.ooh)) * P.Wo + (b * P.osw + P.oow)) * Cout + cout_l) * 4u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) offs[rq * 4 + j] = (pq && b + j < P.B) ? qoff + (unsigned)(j * pstride) : PIX_OOB;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (wm * MTr + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hq;
+                    const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
+                    const int n = n0 + ti, a = a0 + th, b = b0 + tw;
+                    const bool pv = (n < P.N) && (a < P.A) && (b < P.B);
+                    offs[r] = pv ? (unsigned)(((n * P.Ho + (a * P.osh + P.ooh)) * P.Wo + (b * P.osw + P.oow)) * Cout + cout_l) * 4u : PIX_OOB;
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float old[16];
+                if (accum) {   // all sixteen loads in flight before the first add
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, (int)(offs[r] + cofs[nt]), 0, 0));
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned off = offs[r] + cofs[nt];
+                    float v = acc[mt][nt][r] + bias_v[nt];
+                    if (accum) v += old[r];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, (int)off, 0, 0);
+                    const double dv = off < CH_OOB ? (double)v : 0.0;
+                    ssum[nt] += dv;
+                    ssq[nt] += dv * dv;
+                    acc[mt][nt][r] = 0.f;
+                }
+            }
+        }
+        if (P.stats) {   // per-tile BatchNorm partials, combined in fp64 (deterministic: no atomics)
+            double* red = (double*)((char*)smem + redbase);   // [wave][NT*32][2]; readers of the previous tile's partials
+                                                              // are separated from these writes by the work-loop barrier
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                double s = ssum[nt] + __shfl_xor(ssum[nt], 32);
+                double q = ssq[nt] + __shfl_xor(ssq[nt], 32);
+                if (half == 0) {
+                    red[((wave * NT + nt) * 32 + l31) * 2 + 0] = s;
+                    red[((wave * NT + nt) * 32 + l31) * 2 + 1] = q;
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x < NTC) {
+                const int cw = threadIdx.x / (NT * 32);            // which wave column owns this channel
+                const int nt = (threadIdx.x >> 5) % NT, c = threadIdx.x & 31;
+                const int co = ntile * NTC + threadIdx.x;
+                if (co < Cout) {
+                    double s = 0.0, q = 0.0;
+                    for (int wr = 0; wr < (4 >> lwn); ++wr) {           // fixed order over the wave rows
+                        const int w = (wr << lwn) + cw;
+                        s += red[((w * NT + nt) * 32 + c) * 2 + 0];
+                        q += red[((w * NT + nt) * 32 + c) * 2 + 1];
+                    }
+                    double BPB_GLOBAL* gs = (double BPB_GLOBAL*)P.stats;
+                    gs[((size_t)mtile * 2 + 0) * Cout + co] = s;
+                    gs[((size_t)mtile * 2 + 1) * Cout + co] = q;
+                }
+            }
         }
     };
 
-    if (dma) dma_issue(0, 0);
-    int chunk = 0;
-    for (int cb = 0; cb < Cin; cb += CK, ++chunk) {
-        __syncthreads();   // dma: chunk `chunk` has landed (the barrier drains vmcnt) and the other buffer is free again
-        int bufoff = 0;
+    // ---- work loop over (M tile, channel chunk) items
+    if (wres) {
+        for (int c = 0; c < nch; ++c) {
+            if (dma) dma_weights(c * CK, c);
+            else sync_weights(c * CK, c);
+        }
+    }
+    if (dma && mt_first < mt_last) dma_issue(mt_first, 0, 0);
+    int mtile = mt_first, chunk = 0;
+    const int nwork = (mt_last - mt_first) * nch;
+    for (int w = 0; w < nwork; ++w) {
+        __syncthreads();   // dma: item w has landed (the barrier drains vmcnt) and the other buffer is free again
+        const int cb = chunk * CK;
+        int hoff = 0, wslot = wres ? chunk : 0;
         if (dma) {
-            bufoff = (chunk & 1) * bufbytes;
-            if (cb + CK < Cin) dma_issue(cb + CK, (chunk + 1) & 1);
+            hoff = (w & 1) * halo_pad * 16;
+            if (!wres) wslot = w & 1;
+            if (w + 1 < nwork) {
+                const bool last_chunk = chunk + 1 == nch;
+                dma_issue(last_chunk ? mtile + 1 : mtile, last_chunk ? 0 : cb + CK, (w + 1) & 1);
+            }
         } else {
-            sync_stage(cb);
+            sync_stage(mtile, cb);
             __syncthreads();
         }
-        const char* sA = (const char*)smem + bufoff;
+        const char* sA = (const char*)smem + hoff;
+        const char* sB = (const char*)smem + wbase + wslot * b_pad * 16 + boff_lane;
 
         // scalar iteration state over (tap row i, tap col jj, k-group kg); no table, no global memory access
         int it_i = 0, it_j = 0, it_kg = 0, it_t = 0, it_c4 = 0;
-        auto fetch = [&](f32x4 (&a)[2], f32x4 (&b)[NT]) {
+        auto fetch = [&](f32x4 (&a)[MTr], f32x4 (&b)[NT]) {
             int ldsoff, bo;
             if (C4) {   // Cin == 4: lanes 0-31 take tap 2j, lanes 32-63 tap 2j+1 (phantom tap -> the zero slot)
                 int t = 2 * it_c4 + half;
@@ -180,108 +323,60 @@ __global__ __launch_bounds__(256) void bpb_conv_igemm_kernel(const BpbConvProb* 
             } else {
                 ldsoff = (((P.dh0 + P.dhs * it_i) * HWd + (P.dw0 + P.dws * it_j)) * LD + it_kg * 8) * 4;
                 bo = it_t * tapB + it_kg * 2 * NTC * 16;
-                if (++it_kg == KG) {
-                    it_kg = 0;
-                    ++it_t;
-                    if (++it_j == St) { it_j = 0; ++it_i; }
-                }
+                // branch-free advance of (kg, tap col, tap row): scalar selects, no control flow inside the MFMA loop
+                ++it_kg;
+                const int wk = it_kg == KG ? 1 : 0;
+                it_kg = wk ? 0 : it_kg;
+                it_t += wk;
+                it_j += wk;
+                const int wj = it_j == St ? 1 : 0;
+                it_j = wj ? 0 : it_j;
+                it_i += wj;
             }
-            a[0] = *(const f32x4*)(sA + pixoff[0] + ldsoff);
-            if (MTr > 1) a[1] = *(const f32x4*)(sA + pixoff[1] + ldsoff);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b[nt] = *(const f32x4*)(sA + bo + boff_lane + nt * 32 * 16);
+            for (int mt = 0; mt < MTr; ++mt) a[mt] = *(const f32x4*)(sA + pixoff[mt] + ldsoff);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[nt] = *(const f32x4*)(sB + bo + nt * 32 * 16);
         };
-        auto mma = [&](const f32x4 (&a)[2], const f32x4 (&b)[NT]) {
+        auto mma = [&](const f32x4 (&a)[MTr], const f32x4 (&b)[NT]) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[0][nt] = MFMA32(a[0][i], b[nt][i], acc[0][nt]);
-                if (MTr > 1) {
+                for (int mt = 0; mt < MTr; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[1][nt] = MFMA32(a[1][i], b[nt][i], acc[1][nt]);
-                }
-            }
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = MFMA32(a[mt][i], b[nt][i], acc[mt][nt]);
         };
         // ping-pong operand sets: the LDS reads of k-group j+1 are in flight while the 8*NT MFMAs of k-group j run
-        f32x4 a0[2], b0[NT], a1[2], b1[NT];
-        if (nj > 0) fetch(a0, b0);   // nj == 0: empty tap set (a parity class of a strided 1x1 dgrad) -> zeros
-        for (int j = 0; j < nj; j += 2) {
-            if (j + 1 < nj) fetch(a1, b1);
-            mma(a0, b0);
-            if (j + 1 < nj) {
-                if (j + 2 < nj) fetch(a0, b0);
+        f32x4 a0[MTr], b0[NT], a1[MTr], b1[NT];
+        if (nj > 0) {                // nj == 0: empty tap set (a parity class of a strided 1x1 dgrad) -> zeros
+            fetch(a0, b0);
+            int j = 0;
+            for (; j + 2 < nj; j += 2) {   // steady state: straight-line, counted lgkmcnt waits
+                fetch(a1, b1);
+                __builtin_amdgcn_sched_barrier(0);   // keep the ds_reads of group j+1 ahead of the MFMAs of group j
+                mma(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
                 mma(a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (j + 1 < nj) {
+                fetch(a1, b1);
+                mma(a0, b0);
+                mma(a1, b1);
+            } else {
+                mma(a0, b0);
             }
         }
-    }
-
-    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const bpb_gf gy = (bpb_gf)P.y;
-    const bpb_gcf gbias = (bpb_gcf)P.bias;
-    double ssum[NT], ssq[NT];
-    float bias_v[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        ssum[nt] = 0.0;
-        ssq[nt] = 0.0;
-        bias_v[nt] = (gbias && cout_l + nt * 32 < Cout) ? gbias[cout_l + nt * 32] : 0.f;
-    }
-    const bool accum = P.accumulate != 0;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        if (mt >= MTr) break;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int m = (wm * MTr + mt) * 32 + row;
-            const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
-            const int n = n0 + ti, a = a0 + th, b = b0 + tw;
-            const bool pv = (n < P.N) && (a < P.A) && (b < P.B);
-            const size_t obase = (((size_t)n * P.Ho + (a * P.osh + P.ooh)) * P.Wo + (b * P.osw + P.oow)) * Cout;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int co = cout_l + nt * 32;
-                if (pv && co < Cout) {
-                    float v = acc[mt][nt][r] + bias_v[nt];
-                    if (accum) v += gy[obase + co];
-                    gy[obase + co] = v;
-                    ssum[nt] += (double)v;
-                    ssq[nt] += (double)v * (double)v;
-                }
-            }
-        }
-    }
-    if (P.stats) {   // per-tile BatchNorm partials, combined in fp64 (deterministic: no atomics)
-        __syncthreads();
-        double* red = (double*)smem;   // [wave][NT*32][2]
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            double s = ssum[nt] + __shfl_xor(ssum[nt], 32);
-            double q = ssq[nt] + __shfl_xor(ssq[nt], 32);
-            if (half == 0) {
-                red[((wave * NT + nt) * 32 + l31) * 2 + 0] = s;
-                red[((wave * NT + nt) * 32 + l31) * 2 + 1] = q;
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < NTC) {
-            const int cw = threadIdx.x / (NT * 32);            // which wave column owns this channel
-            const int nt = (threadIdx.x >> 5) % NT, c = threadIdx.x & 31;
-            const int co = ntile * NTC + threadIdx.x;
-            if (co < Cout) {
-                double s = 0.0, q = 0.0;
-                for (int wr = 0; wr < (4 >> lwn); ++wr) {           // fixed order over the wave rows
-                    const int w = (wr << lwn) + cw;
-                    s += red[((w * NT + nt) * 32 + c) * 2 + 0];
-                    q += red[((w * NT + nt) * 32 + c) * 2 + 1];
-                }
-                double BPB_GLOBAL* gs = (double BPB_GLOBAL*)P.stats;
-                gs[((size_t)mtile * 2 + 0) * Cout + co] = s;
-                gs[((size_t)mtile * 2 + 1) * Cout + co] = q;
-            }
+        if (++chunk == nch) {
+            epilogue(mtile);
+            chunk = 0;
+            ++mtile;
         }
     }
 }
+
 
 // ---------------------------------------------------------------------------------------
 // Weight gradient:  dW[t][ci][co] = sum_{n,a,b} x[n, a*sa+dh_t+ih0, b*sa+dw_t+iw0, ci] * dy[n,a,b,co]
@@ -549,8 +644,9 @@ static int conv_lds_bytes(const BpbConvProb& p)
     const int ntaps = p.Rt * p.St + (p.Cin == 4 ? 1 : 0);
     const int halo_pad = (npix * (p.LD / 4) + 255) & ~255;
     const int b_pad = (ntaps * (p.CK / 4) * ((p.nt * 32) << p.lwn) + 255) & ~255;
-    int b = (halo_pad + b_pad) * 16 * (p.dma ? 2 : 1);   // halo image + weight tile (two buffers for the DMA pipeline)
-    return b < 8192 ? 8192 : b;
+    const int nbuf = p.dma ? 2 : 1;                      // two halo images for the DMA pipeline
+    const int nwb = p.wres ? p.Cin / p.CK : nbuf;        // resident weight tiles, or one per buffer
+    return (nbuf * halo_pad + nwb * b_pad) * 16 + 4096;  // + BatchNorm partials scratch
 }
 
 extern "C" {
@@ -563,10 +659,14 @@ int bpb_conv_init(void)
         hipError_t e = hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         if (e != hipSuccess) return bpb_set_error((int)e, "bpb_conv_init: %s", hipGetErrorString(e));            \
     }
-    BPB_ATTR((bpb_conv_igemm_kernel<1, false>))
-    BPB_ATTR((bpb_conv_igemm_kernel<2, false>))
-    BPB_ATTR((bpb_conv_igemm_kernel<1, true>))
-    BPB_ATTR((bpb_conv_igemm_kernel<2, true>))
+    BPB_ATTR((bpb_conv_igemm_kernel<1, false, 1>))
+    BPB_ATTR((bpb_conv_igemm_kernel<2, false, 1>))
+    BPB_ATTR((bpb_conv_igemm_kernel<1, true, 1>))
+    BPB_ATTR((bpb_conv_igemm_kernel<2, true, 1>))
+    BPB_ATTR((bpb_conv_igemm_kernel<1, false, 2>))
+    BPB_ATTR((bpb_conv_igemm_kernel<2, false, 2>))
+    BPB_ATTR((bpb_conv_igemm_kernel<1, true, 2>))
+    BPB_ATTR((bpb_conv_igemm_kernel<2, true, 2>))
     BPB_ATTR((bpb_conv_wgrad_kernel<1, 1>))
     BPB_ATTR((bpb_conv_wgrad_kernel<9, 1>))
     BPB_ATTR((bpb_conv_wgrad_kernel<1, 2>))
@@ -580,7 +680,7 @@ int bpb_conv_init(void)
 int bpb_conv_igemm(const BpbConvProb* d_probs, const BpbConvProb* h_probs, int nprobs, hipStream_t stream)
 {
     BPB_REQUIRE(nprobs >= 1 && nprobs <= 16, "bpb_conv_igemm: nprobs=%d out of range", nprobs);
-    int nblk = 0, lds = 0, nt = 0;
+    int nblk = 0, lds = 0, nt = 0, mt = 0;
     const bool c4 = h_probs[0].Cin == 4;
     for (int i = 0; i < nprobs; ++i) {
         const BpbConvProb& p = h_probs[i];
@@ -590,6 +690,7 @@ int bpb_conv_igemm(const BpbConvProb* d_probs, const BpbConvProb* h_probs, int n
         BPB_REQUIRE(p.LD >= p.CK && p.LD % 4 == 0, "bpb_conv_igemm: bad LDS pitch %d", p.LD);
         BPB_REQUIRE(p.x_bytes > 0 && p.w_bytes > 0 && p.x_bytes < 0xFFFFFFF0u && p.w_bytes < 0xFFFFFFF0u,
                     "bpb_conv_igemm: tensors addressed through a buffer descriptor must be < 4 GiB");
+        BPB_REQUIRE((double)p.N * p.Ho * p.Wo * p.Cout * 4.0 <= 1073741824.0, "bpb_conv_igemm: output tensor must be <= 1 GiB");
         BPB_REQUIRE((p.mt_r == 1 || p.mt_r == 2) && (p.lwn == 0 || p.lwn == 1), "bpb_conv_igemm: bad tile shape mt=%d lwn=%d", p.mt_r, p.lwn);
         BPB_REQUIRE((1 << (p.lTI + p.lTH + p.lTW)) == (4 >> p.lwn) * p.mt_r * 32, "bpb_conv_igemm: M tile / wave layout mismatch");
         BPB_REQUIRE(p.nt == 1 || p.nt == 2, "bpb_conv_igemm: nt=%d", p.nt);
@@ -600,19 +701,25 @@ int bpb_conv_igemm(const BpbConvProb* d_probs, const BpbConvProb* h_probs, int n
         const int this_nt = p.nt;
         BPB_REQUIRE(nt == 0 || nt == this_nt, "bpb_conv_igemm: mixed N-tile widths in one group");
         nt = this_nt;
+        BPB_REQUIRE(mt == 0 || mt == p.mt_r, "bpb_conv_igemm: mixed M sub-tile counts in one group");
+        mt = p.mt_r;
         BPB_REQUIRE(p.n_ntiles == bpb_cdiv(p.Cout, (32 * nt) << p.lwn), "bpb_conv_igemm: n_ntiles mismatch");
-        nblk += p.n_mtiles * p.n_ntiles;
+        BPB_REQUIRE(p.tpb >= 1 && (p.wres == 0 || p.wres == 1), "bpb_conv_igemm: tpb=%d wres=%d", p.tpb, p.wres);
+        nblk += bpb_cdiv(p.n_mtiles, p.tpb) * p.n_ntiles;
         const int l = conv_lds_bytes(p);
         lds = l > lds ? l : lds;
     }
     BPB_REQUIRE(lds <= 160 * 1024, "bpb_conv_igemm: halo tile needs %d B of LDS", lds);
     if (nblk == 0) return 0;
-#define BPB_CONV_LAUNCH(NT, C4) \
-    hipLaunchKernelGGL((bpb_conv_igemm_kernel<NT, C4>), dim3(nblk), dim3(256), lds, stream, d_probs, nprobs)
-    if (c4 && nt == 1) { BPB_CONV_LAUNCH(1, true); }
-    else if (c4) { BPB_CONV_LAUNCH(2, true); }
-    else if (nt == 1) { BPB_CONV_LAUNCH(1, false); }
-    else { BPB_CONV_LAUNCH(2, false); }
+#define BPB_CONV_LAUNCH(NT, C4, MT) \
+    hipLaunchKernelGGL((bpb_conv_igemm_kernel<NT, C4, MT>), dim3(nblk), dim3(256), lds, stream, d_probs, nprobs)
+#define BPB_CONV_LAUNCH_MT(NT, C4) \
+    do { if (mt == 1) { BPB_CONV_LAUNCH(NT, C4, 1); } else { BPB_CONV_LAUNCH(NT, C4, 2); } } while (0)
+    if (c4 && nt == 1) { BPB_CONV_LAUNCH_MT(1, true); }
+    else if (c4) { BPB_CONV_LAUNCH_MT(2, true); }
+    else if (nt == 1) { BPB_CONV_LAUNCH_MT(1, false); }
+    else { BPB_CONV_LAUNCH_MT(2, false); }
+#undef BPB_CONV_LAUNCH_MT
 #undef BPB_CONV_LAUNCH
     BPB_LAUNCH_OK();
     return 0;

@@ -12,6 +12,7 @@ Graph vocabulary (all tensors NHWC fp32):
     concat    bilinear align_corners upsample of several maps into channel slices of one map (HRNet head)
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -115,6 +116,9 @@ class Net:
         self.cur_slot = 0          # stream slot of the nodes being recorded (branch-level concurrency)
         self.debug_convs = []      # (ConvProb, x, packed w, y) -- lets the CPU tests emulate the descriptors
         self.debug_wgrads = []     # (WgradProb, ConvNode)
+        # Several M tiles per workgroup (BpbConvProb.tpb/wres) is implemented and tested, but measured slower than two
+        # co-resident single-tile workgroups per CU on every HRNet shape -> off unless requested.
+        self.multi_tile = os.environ.get('BPB_MULTI_TILE', '0') == '1'
 
     # ------------------------------------------------------------------ graph construction
     def _node(self, kind, payload):
@@ -238,8 +242,9 @@ class Net:
         ntaps_b = rt * st + (1 if cin == 4 else 0)
         pad256 = lambda v_: (v_ + 255) // 256 * 256
 
-        def lds_bytes(ck_, ld_, nbuf):
-            return (pad256(ti * hh * hw * (ld_ // 4)) + pad256(ntaps_b * (ck_ // 4) * ntc)) * 16 * nbuf
+        def lds_bytes(ck_, ld_, nbuf, wres_=0):
+            nwb = (cin // ck_) if wres_ else nbuf
+            return (pad256(ti * hh * hw * (ld_ // 4)) * nbuf + pad256(ntaps_b * (ck_ // 4) * ntc) * nwb) * 16 + 4096
         # Channel chunk CK: prefer the double-buffered DMA pipeline with two workgroups per CU (2 images <= 78 KB each
         # workgroup), then DMA with one workgroup per CU, then synchronous staging.
         if cin == 4:
@@ -247,6 +252,8 @@ class Net:
         else:
             cks = [c_ for c_ in (32, 16, 8) if cin % c_ == 0]
             assert cks, 'Cin must be 4 or a multiple of 8'
+        if getattr(self, 'force_ck', None) and cin != 4 and cin % self.force_ck == 0:
+            cks = [self.force_ck]
         ld_of = lambda c_: 4 if cin == 4 else c_ + 4
         dma = 1 if getattr(self, 'use_dma', True) else 0
         choice = None
@@ -261,6 +268,27 @@ class Net:
             assert fit, 'conv tile (halo + weights) exceeds LDS'
             choice = (fit[0], 0)
         ck, dma = choice
+        # Tiles per workgroup: when the launch has more tiles than the chip holds workgroups at once, let each workgroup walk
+        # several consecutive M tiles (the next halo streams in during the MFMA loop and the epilogue of the current one) and
+        # keep the weight tiles of every channel chunk resident in LDS if they fit.
+        n_mt = (-(-n // ti)) * (-(-a // th)) * (-(-b // tw))
+        n_nt = -(-cout // ntc)
+        tpb, wres = 1, 0
+        multi = getattr(self, 'multi_tile', True) and cin != 4
+        if multi:
+            for wres_try in (1, 0):
+                lds_ = lds_bytes(ck, ld_of(ck), 2 if dma else 1, wres_try)
+                if lds_ > 160 * 1024:
+                    continue
+                resident = 256 * max(1, min(2, (160 * 1024) // lds_))
+                t_ = min(8, -(-(n_mt * n_nt) // resident))
+                if t_ > 1:
+                    tpb, wres = t_, wres_try
+                break
+        forced_tpb = getattr(self, 'force_tpb', None)
+        if forced_tpb is not None and cin != 4:
+            tpb, wres = forced_tpb
+            assert lds_bytes(ck, ld_of(ck), 2 if dma else 1, wres) <= 160 * 1024
         ld = ld_of(ck)
         p = ConvProb()
         p.x, p.w, p.y = x_buf.data_ptr(), w_packed.data_ptr(), y_buf.data_ptr()
@@ -286,6 +314,7 @@ class Net:
         p.w_bytes = w_packed.numel() * 4
         p.magic_spp = magic(ld // 4)
         p.magic_hw, p.magic_hh = magic(hw), magic(hh)
+        p.tpb, p.wres = tpb, wres
         if stats is not None:
             st_buf = torch.empty(p.n_mtiles * 2 * cout, device=self.device, dtype=torch.float64)
             p.stats = st_buf.data_ptr()
@@ -296,7 +325,7 @@ class Net:
     def _emit_conv(self, plans, prob, label):
         dev = self._dev_struct(prob)
         op = self._op(nv.OP_CONV, ints=(1,), ptrs=(dev, C.addressof(prob)))
-        variant = 'bpb_conv_igemm_kernel<%d,%s>' % (prob.nt, 'true' if prob.Cin == 4 else 'false')
+        variant = 'bpb_conv_igemm_kernel<%d,%s,%d>' % (prob.nt, 'true' if prob.Cin == 4 else 'false', prob.mt_r)
         npix = prob.N * prob.A * prob.B
         flops = 2.0 * npix * prob.Rt * prob.St * prob.Cin * prob.Cout
         bytes_ = 4.0 * (prob.N * prob.Hi * prob.Wi * prob.Cin + npix * prob.Cout)
@@ -549,7 +578,9 @@ class Net:
         halo_pad = ((1 << wp.lTI) * wp.HH * wp.HW * (wp.LD // 4) + 255) // 256 * 256
         lds1 = (halo_pad + 128 * 8 * ntw) * 16
         assert lds1 <= 160 * 1024, 'wgrad tile exceeds LDS'
-        wp.dma = 1 if (getattr(self, 'use_dma', True) and 2 * lds1 <= 160 * 1024) else 0
+        # measured on MI355X: the DMA double buffer pays for 1x1 filters (small tiles, 2 workgroups/CU still fit) and loses
+        # for 3x3 ones, where two halo images leave one workgroup per CU (65 us vs 53 us on 32->32 @ 64x32, N=64)
+        wp.dma = 1 if (getattr(self, 'use_dma', True) and t == 1 and 2 * lds1 <= 160 * 1024) else 0
         wp.x_bytes, wp.dy_bytes = x.buf.numel() * 4, gy.numel() * 4
         wp.magic_spp = magic(wp.LD // 4)
         elems = wp.nsplit * t * x.C * cout

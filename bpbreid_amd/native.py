@@ -22,7 +22,7 @@ class ConvProb(C.Structure):
             'Rt', 'St', 'dh0', 'dhs', 'dw0', 'dws', 'w0', 'wrs', 'wss', 'lTI', 'lTH', 'lTW', 'HH', 'HW', 'CK', 'LD',
             'tiles_a', 'tiles_b', 'n_mtiles', 'n_ntiles', 'blk_begin', 'accumulate', 'dma')] + [
         ('x_bytes', C.c_uint), ('w_bytes', C.c_uint), ('magic_spp', C.c_uint), ('mt_r', C.c_int), ('lwn', C.c_int), ('nt', C.c_int),
-        ('magic_hw', C.c_uint), ('magic_hh', C.c_uint)]
+        ('magic_hw', C.c_uint), ('magic_hh', C.c_uint), ('tpb', C.c_int), ('wres', C.c_int)]
 
 
 class WgradProb(C.Structure):

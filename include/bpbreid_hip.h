@@ -62,6 +62,8 @@ typedef struct BpbConvProb {
     unsigned magic_spp;     // ceil(2^32 / (LD/4))
     int mt_r, lwn, nt;      // wave tile: mt_r 32-pixel sub-tiles (1|2), 2^lwn waves along channels (lwn 0|1), nt 32-channel sub-tiles (1|2)
     unsigned magic_hw, magic_hh;   // ceil(2^32/d) for d = HW, HH (staging index split without idiv)
+    int tpb;                // consecutive M tiles walked by one workgroup (>= 1); grid = ceil(n_mtiles / tpb) * n_ntiles
+    int wres;               // 1: the weight tiles of all Cin/CK chunks stay resident in LDS for the whole workgroup
 } BpbConvProb;
 
 /* weight-gradient problem: dW[t][ci][co] = sum_{n,a,b} x[n, a*sa + t/S + ih0, b*sa + t%S + iw0, ci] * dy[n,a,b,co] */
