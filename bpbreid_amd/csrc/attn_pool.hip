@@ -343,14 +343,25 @@ __global__ __launch_bounds__(256) void bpb_head_bwd_params_kernel(const float* _
         if (threadIdx.x == 0) L[k] = red[0];
         __syncthreads();
     }
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c < C) {
+    // block = 32 channels x 8 partial-sum lanes: lane ql adds the pooling partials q = ql, ql + 8, ... (coalesced over the
+    // channels), the 8 lane sums are combined in a fixed order through LDS -> deterministic
+    __shared__ double araw_s[BPB_HEAD_MAXJ][8][32];
+    const int cl = threadIdx.x & 31, ql = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    for (int k = 0; k < K1; ++k) {
+        double a = 0.0;
+        if (c < C)
+            for (int q = ql; q < nparts; q += 8) a += (double)part[((long)q * K1 + k) * C + c];
+        araw_s[k][ql][cl] = a;
+    }
+    __syncthreads();
+    if (ql == 0 && c < C) {
         const double M = (double)npix_total;
         double s1 = 0.0, s2 = 0.0;
         const float g = gamma[c], b = beta[c], mu = mean[c], is = invstd[c];
         for (int k = 0; k < K1; ++k) {
             double araw = 0.0;
-            for (int q = 0; q < nparts; ++q) araw += (double)part[((long)q * K1 + k) * C + c];
+            for (int q = 0; q < 8; ++q) araw += araw_s[k][q][cl];
             const double a = (araw - (double)mu * L[k]) * (double)is;
             const double w = (double)W[(long)k * C + c];
             s1 += w * L[k];
@@ -578,7 +589,7 @@ int bpb_head_bwd_params(const float* part, int nparts, const double* lpart, int 
                         const float* gamma, const float* beta, const float* mean, const float* invstd, float* dW,
                         float* dbias, float* dgamma, float* dbeta, float* k1, float* k2, int accumulate, hipStream_t stream)
 {
-    hipLaunchKernelGGL(bpb_head_bwd_params_kernel, dim3(bpb_cdiv(C, 256)), dim3(256), 0, stream, part, nparts, lpart, nlpart,
+    hipLaunchKernelGGL(bpb_head_bwd_params_kernel, dim3(bpb_cdiv(C, 32)), dim3(256), 0, stream, part, nparts, lpart, nlpart,
                        (long)N * HW, HW, K1, C, W, gamma, beta, mean, invstd, dW, dbias, dgamma, dbeta, k1, k2, accumulate);
     BPB_LAUNCH_OK();
     return 0;
