@@ -101,11 +101,13 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_igemm_kernel(const BpbConvPro
     const int tapB = qn * NTC * 16;            // bytes per tap in the weight region
     const int boff_lane = (C4 ? 0 : half * NTC * 16) + (wni * NT * 32 + l31) * 16;
 
-    // byte offset of slot `idx` of chunk `cb` inside x / w; 0xFFFFFFF0 = "out of range" (buffer loads return 0 there)
+    // byte offset of slot `idx` of chunk `cb` inside x / w; DMA_OOB = "out of range" (buffer loads return 0 there).  x and w
+    // are < 2 GiB (host check), so DMA_OOB plus any per-chunk increment is still beyond the descriptor's range.
+    constexpr unsigned DMA_OOB = 0x80000000u;
     auto halo_voff = [&](int idx, int cb, int n0, int a0, int b0) -> unsigned {
         const unsigned hp = bpb_fdiv((unsigned)idx, spp, P.magic_spp);
         const int v = idx - hp * spp;
-        if (idx >= halo_slots || v >= qn) return 0xFFFFFFF0u;
+        if (idx >= halo_slots || v >= qn) return DMA_OOB;
         const unsigned t = bpb_fdiv(hp, HWd, P.magic_hw);
         const int hc = hp - t * HWd;
         const unsigned ti = bpb_fdiv(t, HH, P.magic_hh);
@@ -113,14 +115,14 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_igemm_kernel(const BpbConvPro
         const int n = n0 + (int)ti, ih = a0 * sa + hr + P.ih0, iw = b0 * sa + hc + P.iw0;
         if (n < P.N && (unsigned)ih < (unsigned)P.Hi && (unsigned)iw < (unsigned)P.Wi)
             return ((((unsigned)n * P.Hi + ih) * P.Wi + iw) * Cin + cb + v * 4) * 4u;
-        return 0xFFFFFFF0u;
+        return DMA_OOB;
     };
     auto b_voff = [&](int bi, int cb) -> unsigned {
         const int n = bi & (NTC - 1);
         const int r = bi >> lNTC;
         const int q = r & (qn - 1);
         const int t = r >> lvpp;
-        if (bi >= nB || t >= ntaps) return 0xFFFFFFF0u;
+        if (bi >= nB || t >= ntaps) return DMA_OOB;
         const int ti_ = t / St, tj_ = t - ti_ * St;
         const int widx = P.w0 + P.wrs * ti_ + P.wss * tj_;
         const int co = min(ntile * NTC + n, Cout - 1);     // columns >= Cout are never stored
@@ -132,24 +134,64 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_igemm_kernel(const BpbConvPro
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)P.x, 0, (int)P.x_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)P.w, 0, (int)P.w_bytes, 0x00020000);
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    auto dma_weights = [&](int cb, int slot) {
-        char* base = (char*)smem + wbase + slot * b_pad * 16 + wave * 1024;
-        for (int b0s = 0; b0s < b_pad; b0s += 256)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(base + b0s * 16), 16,
-                                                     (int)b_voff(b0s + (int)threadIdx.x, cb), 0, 0, 0);
-    };
     auto tile_origin = [&](int mtile, int& n0, int& a0, int& b0) {
         const int tb = mtile % P.tiles_b, t2 = mtile / P.tiles_b;
         const int ta = t2 % P.tiles_a, tn = t2 / P.tiles_a;
         n0 = tn << lTI; a0 = ta << lTH; b0 = tb << lTW;
     };
-    auto dma_issue = [&](int mtile, int cb, int buf) {
+    // The offsets of a thread's DMA pieces depend on the chunk only through a constant increment (cb channels of x,
+    // cb/4 channel quads of w): they are computed once per tile (~30 VALU instructions each) and kept in registers when
+    // the image has at most DMA_HS + DMA_WS pieces per thread; a chunk then costs one add per piece.
+    constexpr int DMA_HS = 12, DMA_WS = 12;
+    const int nhs = halo_pad >> 8, nws = b_pad >> 8;
+    const bool pre = dma && P.tpb == 1 && nhs <= DMA_HS && nws <= DMA_WS;   // (recomputing per tile in the loop costs 70 VGPRs)
+    unsigned hofs[DMA_HS], wofs[DMA_WS];
+    auto compute_hofs = [&](int mtile) {
         int n0, a0, b0;
         tile_origin(mtile, n0, a0, b0);
+#pragma unroll
+        for (int k = 0; k < DMA_HS; ++k) {
+            hofs[k] = k < nhs ? halo_voff(k * 256 + (int)threadIdx.x, 0, n0, a0, b0) : DMA_OOB;
+            __builtin_amdgcn_sched_barrier(0);   // one piece at a time: interleaving all twelve costs ~100 VGPRs
+        }
+    };
+    if (pre) {
+        compute_hofs(mt_first);
+#pragma unroll
+        for (int k = 0; k < DMA_WS; ++k) {
+            wofs[k] = k < nws ? b_voff(k * 256 + (int)threadIdx.x, 0) : DMA_OOB;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    auto dma_weights = [&](int cb, int slot) {
+        char* base = (char*)smem + wbase + slot * b_pad * 16 + wave * 1024;
+        if (pre) {
+            const unsigned inc = (unsigned)((cb >> 2) * Cout * 16);
+#pragma unroll
+            for (int k = 0; k < DMA_WS; ++k)
+                if (k < nws)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(base + k * 4096), 16, (int)(wofs[k] + inc), 0, 0, 0);
+        } else {
+            for (int b0s = 0; b0s < b_pad; b0s += 256)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(base + b0s * 16), 16,
+                                                         (int)b_voff(b0s + (int)threadIdx.x, cb), 0, 0, 0);
+        }
+    };
+    auto dma_issue = [&](int mtile, int cb, int buf) {
         char* base = (char*)smem + buf * halo_pad * 16 + wave * 1024;     // wave-uniform; lanes land at +16*lane
-        for (int b0s = 0; b0s < halo_pad; b0s += 256)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(base + b0s * 16), 16,
-                                                     (int)halo_voff(b0s + (int)threadIdx.x, cb, n0, a0, b0), 0, 0, 0);
+        if (pre) {
+            const unsigned inc = (unsigned)(cb * 4);
+#pragma unroll
+            for (int k = 0; k < DMA_HS; ++k)
+                if (k < nhs)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(base + k * 4096), 16, (int)(hofs[k] + inc), 0, 0, 0);
+        } else {
+            int n0, a0, b0;
+            tile_origin(mtile, n0, a0, b0);
+            for (int b0s = 0; b0s < halo_pad; b0s += 256)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(base + b0s * 16), 16,
+                                                         (int)halo_voff(b0s + (int)threadIdx.x, cb, n0, a0, b0), 0, 0, 0);
+        }
         if (!wres) dma_weights(cb, buf);
     };
     // (b) synchronous path (fallback when the double-buffered image does not fit in LDS)
@@ -157,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_igemm_kernel(const BpbConvPro
         for (int bi = threadIdx.x; bi < b_pad; bi += 256) {
             const unsigned vo = b_voff(bi, cb);
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (vo != 0xFFFFFFF0u) val = BPB_GLD4((const char BPB_GLOBAL*)P.w + vo);
+            if (vo != DMA_OOB) val = BPB_GLD4((const char BPB_GLOBAL*)P.w + vo);
             *(f32x4*)((char*)smem + wbase + (slot * b_pad + bi) * 16) = val;
         }
     };
@@ -167,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_igemm_kernel(const BpbConvPro
         for (int idx = threadIdx.x; idx < halo_pad; idx += 256) {
             const unsigned vo = halo_voff(idx, cb, n0, a0, b0);
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (vo != 0xFFFFFFF0u) val = BPB_GLD4((const char BPB_GLOBAL*)P.x + vo);
+            if (vo != DMA_OOB) val = BPB_GLD4((const char BPB_GLOBAL*)P.x + vo);
             *(f32x4*)((char*)smem + idx * 16) = val;
         }
         if (!wres) sync_weights(cb, 0);
@@ -310,7 +352,9 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_igemm_kernel(const BpbConvPro
         const char* sB = (const char*)smem + wbase + wslot * b_pad * 16 + boff_lane;
 
         // scalar iteration state over (tap row i, tap col jj, k-group kg); no table, no global memory access
-        int it_i = 0, it_j = 0, it_kg = 0, it_t = 0, it_c4 = 0;
+        int it_j = 0, it_kg = 0, it_c4 = 0;
+        int ldsoff_s = ((P.dh0 * HWd + P.dw0) * LD) * 4, bo_s = 0;        // running offsets of the next k-group (non-C4)
+        const int stepj = P.dws * LD * 4 - KG * 32, stepi = (P.dhs * HWd - St * P.dws) * LD * 4;
         auto fetch = [&](f32x4 (&a)[MTr], f32x4 (&b)[NT]) {
             int ldsoff, bo;
             if (C4) {   // Cin == 4: lanes 0-31 take tap 2j, lanes 32-63 tap 2j+1 (phantom tap -> the zero slot)
@@ -321,17 +365,18 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_igemm_kernel(const BpbConvPro
                 ldsoff = (((P.dh0 + P.dhs * ti_) * HWd + (P.dw0 + P.dws * tj_)) * LD) * 4;
                 ++it_c4;
             } else {
-                ldsoff = (((P.dh0 + P.dhs * it_i) * HWd + (P.dw0 + P.dws * it_j)) * LD + it_kg * 8) * 4;
-                bo = it_t * tapB + it_kg * 2 * NTC * 16;
-                // branch-free advance of (kg, tap col, tap row): scalar selects, no control flow inside the MFMA loop
+                ldsoff = ldsoff_s;
+                bo = bo_s;
+                // branch-free advance over (k-group, tap column, tap row): the weight tile is contiguous in that order
+                // (tapB == KG * 2 * NTC * 16), the halo offset takes one of three strides
+                bo_s += 2 * NTC * 16;
                 ++it_kg;
-                const int wk = it_kg == KG ? 1 : 0;
+                const bool wk = it_kg == KG;
                 it_kg = wk ? 0 : it_kg;
-                it_t += wk;
-                it_j += wk;
-                const int wj = it_j == St ? 1 : 0;
+                it_j += wk ? 1 : 0;
+                const bool wj = it_j == St;
                 it_j = wj ? 0 : it_j;
-                it_i += wj;
+                ldsoff_s += 32 + (wk ? stepj : 0) + (wj ? stepi : 0);
             }
 #pragma unroll
             for (int mt = 0; mt < MTr; ++mt) a[mt] = *(const f32x4*)(sA + pixoff[mt] + ldsoff);
@@ -688,8 +733,8 @@ int bpb_conv_igemm(const BpbConvProb* d_probs, const BpbConvProb* h_probs, int n
         BPB_REQUIRE(p.CK >= 4 && p.CK <= 32 && (p.CK & (p.CK - 1)) == 0 && p.Cin % p.CK == 0 && (p.Cin == 4 || p.CK >= 8),
                     "bpb_conv_igemm: bad channel chunk CK=%d for Cin=%d", p.CK, p.Cin);
         BPB_REQUIRE(p.LD >= p.CK && p.LD % 4 == 0, "bpb_conv_igemm: bad LDS pitch %d", p.LD);
-        BPB_REQUIRE(p.x_bytes > 0 && p.w_bytes > 0 && p.x_bytes < 0xFFFFFFF0u && p.w_bytes < 0xFFFFFFF0u,
-                    "bpb_conv_igemm: tensors addressed through a buffer descriptor must be < 4 GiB");
+        BPB_REQUIRE(p.x_bytes > 0 && p.w_bytes > 0 && p.x_bytes < 0x80000000u && p.w_bytes < 0x80000000u,
+                    "bpb_conv_igemm: tensors addressed through a buffer descriptor must be < 2 GiB");
         BPB_REQUIRE((double)p.N * p.Ho * p.Wo * p.Cout * 4.0 <= 1073741824.0, "bpb_conv_igemm: output tensor must be <= 1 GiB");
         BPB_REQUIRE((p.mt_r == 1 || p.mt_r == 2) && (p.lwn == 0 || p.lwn == 1), "bpb_conv_igemm: bad tile shape mt=%d lwn=%d", p.mt_r, p.lwn);
         BPB_REQUIRE((1 << (p.lTI + p.lTH + p.lTW)) == (4 >> p.lwn) * p.mt_r * 32, "bpb_conv_igemm: M tile / wave layout mismatch");
