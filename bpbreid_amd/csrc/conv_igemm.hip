@@ -551,6 +551,15 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_wgrad_kernel(const BpbWgradPr
         }
     };
 
+    // tile-independent LDS offsets of this lane's 16 k-steps (pixel m = wave*32 + 2*ks + half)
+    int xo[16], mrow[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        const int m = wave * 32 + ks * 2 + half;
+        const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
+        xo[ks] = (((ti * HH + th * sa) * HWd + tw * sa) * LD + l31) * 4;
+        mrow[ks] = m * LDY + l31;
+    }
     if (dma && mt_begin < mt_end) dma_issue(mt_begin, 0);
     for (int mtile = mt_begin; mtile < mt_end; ++mtile) {
         __syncthreads();   // dma: this tile has landed (barrier drains vmcnt) and the other buffer is free
@@ -564,23 +573,33 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_wgrad_kernel(const BpbWgradPr
         }
         const char* sx = (const char*)smem + bufoff;
         const float* sdy = (const float*)(sx + halo_pad * 16);
-        // wave handles pixels [wave*32, wave*32+32): 16 k-steps of 2 pixels
-#pragma unroll 4
-        for (int ks = 0; ks < 16; ++ks) {
-            const int m = wave * 32 + ks * 2 + half;
-            const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
-            const int xo = (((ti * HH + th * sa) * HWd + tw * sa) * LD + l31) * 4;
-            float bfrag[NTW];
+        // wave handles pixels [wave*32, wave*32+32): 16 k-steps of 2 pixels.  Straight-line, software-pipelined: the
+        // TG + NTW ds_reads of step ks+1 issue before the TG*NTW MFMAs of step ks (counted lgkmcnt waits, no branches;
+        // taps past the filter -- only the last group of a 7x7 -- re-read the last valid tap and are never stored).
+        auto fetch = [&](int ks, float (&a)[TG], float (&b)[NTW]) {
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) bfrag[nt] = sdy[m * LDY + nt * 32 + l31];
+            for (int nt = 0; nt < NTW; ++nt) b[nt] = sdy[mrow[ks] + nt * 32];
 #pragma unroll
-            for (int t = 0; t < TG; ++t) {
-                if (t < nt_here) {
-                    const float afrag = *(const float*)(sx + xo + tapoff[t]);
+            for (int t = 0; t < TG; ++t) a[t] = *(const float*)(sx + xo[ks] + tapoff[t]);
+        };
+        auto mma = [&](const float (&a)[TG], const float (&b)[NTW]) {
 #pragma unroll
-                    for (int nt = 0; nt < NTW; ++nt) acc[t][nt] = MFMA32(afrag, bfrag[nt], acc[t][nt]);
-                }
-            }
+            for (int t = 0; t < TG; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[t][nt] = MFMA32(a[t], b[nt], acc[t][nt]);
+        };
+        float a0[TG], b0[NTW], a1[TG], b1[NTW];
+        fetch(0, a0, b0);
+#pragma unroll
+        for (int ks = 0; ks < 16; ks += 2) {
+            fetch(ks + 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 2 < 16) fetch(ks + 2, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     __syncthreads();

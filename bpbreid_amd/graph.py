@@ -580,7 +580,8 @@ class Net:
         assert lds1 <= 160 * 1024, 'wgrad tile exceeds LDS'
         # measured on MI355X: the DMA double buffer pays for 1x1 filters (small tiles, 2 workgroups/CU still fit) and loses
         # for 3x3 ones, where two halo images leave one workgroup per CU (65 us vs 53 us on 32->32 @ 64x32, N=64)
-        wp.dma = 1 if (getattr(self, 'use_dma', True) and t == 1 and 2 * lds1 <= 160 * 1024) else 0
+        wp.dma = 1 if (getattr(self, 'use_dma', True) and (t == 1 or os.environ.get('BPB_WGRAD_DMA3') == '1')
+                       and 2 * lds1 <= 160 * 1024) else 0
         wp.x_bytes, wp.dy_bytes = x.buf.numel() * 4, gy.numel() * 4
         wp.magic_spp = magic(wp.LD // 4)
         elems = wp.nsplit * t * x.C * cout
