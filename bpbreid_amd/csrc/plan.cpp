@@ -15,8 +15,11 @@ static int run_one(const BpbPlanOp& o, int k, hipStream_t stream);
 // low-resolution branches alone cannot fill 256 CUs (a 256-channel 8x4 map at batch 64 yields ~128 workgroups).  Ops carry
 // a stream slot (i[10]); slot 0 is the caller's stream, slots 1..3 are side streams owned by the library.  FORK makes the
 // side streams wait for the main stream, JOIN makes the main stream wait for them (HIP events; also valid under stream
-// capture, so a plan with forks can still be recorded into a hipGraph).
-#define BPB_NSIDE 3
+// capture, so a plan with forks can still be recorded into a hipGraph).  Slots 4..7 are the weight-gradient companions
+// of slots 0..3: the weight gradient of a convolution (MFMA-bound) and its slab reduction are not on the data-gradient
+// chain, so they are handed to the companion stream (DEP) and overlap with the HBM-bound BatchNorm-backward passes of
+// the next layer; one DEP per companion brings them back at the end of the backward plan.
+#define BPB_NSIDE 7
 #define BPB_NEVENTS 64
 static hipStream_t g_side[BPB_NSIDE];
 static hipEvent_t g_events[BPB_NEVENTS];
@@ -64,6 +67,17 @@ extern "C" int bpb_plan_run(const BpbPlanOp* ops, int nops, hipStream_t stream)
             }
             continue;
         }
+        if (o.kind == BPB_OP_DEP) {
+            const int src = o.i[0], dst = o.i[1];
+            if (src < 0 || src > BPB_NSIDE || dst < 0 || dst > BPB_NSIDE)
+                return bpb_set_error(-1, "bpb_plan_run: DEP slots %d -> %d out of range", src, dst);
+            if (src == dst) continue;
+            if (int rc = ensure_streams()) return rc;
+            hipEvent_t e = next_event();
+            (void)hipEventRecord(e, src == 0 ? stream : g_side[src - 1]);
+            (void)hipStreamWaitEvent(dst == 0 ? stream : g_side[dst - 1], e, 0);
+            continue;
+        }
         const int slot = o.i[10];
         hipStream_t st = stream;
         if (slot > 0) {
@@ -88,7 +102,7 @@ extern "C" int bpb_plan_run_timed(const BpbPlanOp* ops, int nops, hipStream_t st
     (void)hipEventRecord(ev[0], stream);
     int rc = 0;
     for (int k = 0; k < nops && rc == 0; ++k) {     // everything on ONE stream: fork/join records are no-ops here
-        if (ops[k].kind != BPB_OP_FORK && ops[k].kind != BPB_OP_JOIN) rc = run_one(ops[k], k, stream);
+        if (ops[k].kind != BPB_OP_FORK && ops[k].kind != BPB_OP_JOIN && ops[k].kind != BPB_OP_DEP) rc = run_one(ops[k], k, stream);
         (void)hipEventRecord(ev[k + 1], stream);
     }
     (void)hipStreamSynchronize(stream);

@@ -119,6 +119,9 @@ class Net:
         # Several M tiles per workgroup (BpbConvProb.tpb/wres) is implemented and tested, but measured slower than two
         # co-resident single-tile workgroups per CU on every HRNet shape -> off unless requested.
         self.multi_tile = os.environ.get('BPB_MULTI_TILE', '0') == '1'
+        self.wgrad_streams = os.environ.get('BPB_WGRAD_STREAMS', '1') != '0'
+        self.interleave = os.environ.get('BPB_INTERLEAVE', '1') != '0'
+        self._side_used = set()
 
     # ------------------------------------------------------------------ graph construction
     def _node(self, kind, payload):
@@ -449,12 +452,45 @@ class Net:
         self.keep.append(ba)
         return ba
 
+    def _interleave(self, ops):
+        """Between a FORK and its JOIN the branches were recorded one after the other.  Re-order the records so that the
+        branch chains advance together (always the chain with the least estimated time issued so far goes next; a chain =
+        a branch slot plus its weight-gradient companion, whose relative order is kept): the host feeds all streams evenly
+        and a captured graph is laid out in the order it should execute."""
+        order, k, n = [], 0, len(ops)
+        est = lambda m: max(m['flops'] / 60e12, m['bytes'] / 3e12) + 4e-6
+        while k < n:
+            order.append(k)
+            if ops[k].kind == nv.OP_FORK:
+                j = k + 1
+                while j < n and ops[j].kind not in (nv.OP_JOIN, nv.OP_FORK):
+                    j += 1
+                if j < n and ops[j].kind == nv.OP_JOIN:
+                    chains = {}
+                    for q in range(k + 1, j):
+                        cid = (ops[q].i[0] if ops[q].kind == nv.OP_DEP else ops[q].i[10]) % 4
+                        chains.setdefault(cid, []).append(q)
+                    clock = {cid: 0.0 for cid in chains}
+                    pos = {cid: 0 for cid in chains}
+                    while any(pos[c_] < len(chains[c_]) for c_ in chains):
+                        cid = min((c_ for c_ in chains if pos[c_] < len(chains[c_])), key=lambda c_: (clock[c_], c_))
+                        q = chains[cid][pos[cid]]
+                        pos[cid] += 1
+                        clock[cid] += est(ops.meta[q])
+                        order.append(q)
+                    k = j
+                    continue
+            k += 1
+        return order
+
     def _freeze(self, ops):
+        order = self._interleave(ops) if getattr(self, 'interleave', True) else list(range(len(ops)))
+        assert sorted(order) == list(range(len(ops)))
         arr = (PlanOp * max(1, len(ops)))()
-        for k, op in enumerate(ops):
-            arr[k] = op
+        for k, q in enumerate(order):
+            arr[k] = ops[q]
         self.keep.append(arr)
-        return arr, len(ops), list(ops.meta)
+        return arr, len(ops), [ops.meta[q] for q in order]
 
     # ------------------------------------------------------------------ backward plan
     def _emit_backward(self):
@@ -495,7 +531,7 @@ class Net:
                     if isinstance(t, ConvNode):
                         bn = t.bn
                         npix = a.N * a.H * a.W
-                        nblocks = max(1, min(512, npix // 64))
+                        nblocks = max(1, min(512, npix // 16))   # >= 128 workgroups even for the 8x4 maps (2048 pixels)
                         part = torch.empty(nblocks * 2 * a.C, device=self.device, dtype=torch.float64)
                         self.keep.append(part)
                         ta.src = a.buf.data_ptr()
@@ -528,8 +564,10 @@ class Net:
                             4.0 * (x.buf.numel() + 1.25 * y.buf.numel()))
             elif kind == 'conv':
                 self._emit_conv_backward(pay, ws_requests)
-        # one split-K slab workspace per stream slot (weight-gradient launches of one slot run back to back)
         bwd.slot = 0
+        for side in sorted(self._side_used):       # bring the weight-gradient streams back before the optimizer
+            bwd.add(self._op(nv.OP_DEP, ints=(side, 0)), 'dep')
+        # one split-K slab workspace per stream slot (weight-gradient launches of one slot run back to back)
         wss = {}
         for elems, prob, slot in ws_requests:
             wss[slot] = max(wss.get(slot, 1), elems)
@@ -572,7 +610,9 @@ class Net:
         wp.n_cotiles = -(-cout // (32 * ntw))
         wp.n_tapgroups = 1 if t == 1 else -(-t // 9)
         pairs = wp.n_citiles * wp.n_cotiles * wp.n_tapgroups
-        wp.nsplit = max(1, min(-(-wp.n_mtiles // 2), -(-512 // pairs)))
+        tpb_w = int(os.environ.get('BPB_WGRAD_TPB', '2'))          # tuning knobs (A/B measurements)
+        blk_w = int(os.environ.get('BPB_WGRAD_BLOCKS', '512'))
+        wp.nsplit = max(1, min(-(-wp.n_mtiles // tpb_w), -(-blk_w // pairs)))
         wp.blk_begin = 0
         wp.magic_hw, wp.magic_hh = magic(wp.HW), magic(wp.HH)
         halo_pad = ((1 << wp.lTI) * wp.HH * wp.HW * (wp.LD // 4) + 255) // 256 * 256
@@ -585,7 +625,15 @@ class Net:
         wp.x_bytes, wp.dy_bytes = x.buf.numel() * 4, gy.numel() * 4
         wp.magic_spp = magic(wp.LD // 4)
         elems = wp.nsplit * t * x.C * cout
-        ws_requests.append((elems, wp, self._bwd_slot))
+        # weight gradient + slab reduction run on the companion stream of this branch (slot + 4): they only need dy (final
+        # at this point) and x, nothing on the data-gradient chain needs them, and the join is at the end of the plan
+        main_slot = self._bwd_slot
+        side_slot = main_slot + 4 if (self.wgrad_streams and main_slot < 4) else main_slot
+        if side_slot != main_slot:
+            bwd.add(self._op(nv.OP_DEP, ints=(main_slot, side_slot)), 'dep')
+            self._side_used.add(side_slot)
+        bwd.slot = side_slot
+        ws_requests.append((elems, wp, side_slot))
         dev = self._dev_struct(wp)
         self._wgrad_descs.append((dev, wp))
         self.debug_wgrads.append((wp, cv))
@@ -596,6 +644,7 @@ class Net:
         red = self._op(nv.OP_WGRAD_REDUCE, ints=(wp.nsplit, t, x.C, cin_real, cout, 0), ptrs=(None, cv.weight.grad))
         self._pending_reduce.append((red, wp))
         bwd.add(red, 'wgrad_reduce', 0, 4.0 * (elems + t * cin_real * cout))
+        bwd.slot = main_slot
         if cv.bias is not None:
             raise NotImplementedError('conv bias gradient on the backbone path')
         # ---- data gradient

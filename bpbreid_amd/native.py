@@ -62,7 +62,7 @@ class PlanOp(C.Structure):
 
 (OP_CONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL_AFFINE, OP_FUSE_FWD, OP_TERM_BWD,
  OP_BN_BWD_FINALIZE, OP_NCHW_TO_NHWC4, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_BILINEAR_FWD, OP_BILINEAR_BWD, OP_FILL,
- OP_CHANNEL_STATS, OP_FORK, OP_JOIN) = range(18)
+ OP_CHANNEL_STATS, OP_FORK, OP_JOIN, OP_DEP) = range(19)
 
 
 def magic(d):

@@ -153,9 +153,12 @@ typedef enum BpbOpKind {
     BPB_OP_CHANNEL_STATS = 15,
     BPB_OP_FORK = 16,
     BPB_OP_JOIN = 17,
+    BPB_OP_DEP = 18,   /* i0 = source slot, i1 = destination slot: work recorded later on `destination` waits for everything
+                          recorded so far on `source` (one event record + one stream wait) */
 } BpbOpKind;
 
-// generic op record; slot meaning per kind is documented next to each case; i[10] = stream slot (0 main, 1..3 side)
+// generic op record; slot meaning per kind is documented next to each case; i[10] = stream slot (0 = the caller's stream, 1..3 = branch streams,
+// 4..7 = the weight-gradient companions of slots 0..3)
 typedef struct BpbPlanOp {
     int kind;
     int i[11];
