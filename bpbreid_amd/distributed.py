@@ -41,3 +41,52 @@ class GradAllReducer:
             w.wait()
         self._work = []
         return 1.0 / self.world
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Evaluation: the gallery is embarrassingly parallel.  Rank r holds gallery rows
+# [gallery_shard(G, world, r)), computes the [Q, G_r] block of the part-based distance matrix against all queries, the
+# "no shared visible part" fill value (global max + 1, distance.py:171) is agreed with ONE scalar all-reduce, and the
+# blocks are all-gathered along the gallery axis.  No other exchange; the [P,Q,G_r] per-part blocks stay local.
+def gallery_shard(n, world, rank):
+    """Contiguous, balanced [begin, end) of rank `rank` (the first n % world ranks get one more row)."""
+    base, rem = divmod(n, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def sharded_part_distance(qf, gf_local, qf_parts_visibility=None, gf_local_parts_visibility=None, dist_combine_strat='mean',
+                          metric='euclidean', group=None, local_fn=None):
+    """-> (distmat [Q, G] identical on every rank, local per-part block [P, Q, G_local]).
+
+    `local_fn(qf, gf_local, qv, gv_local, strat, metric) -> (dist, parts, vmax[1] fp32, mode)` computes one shard with
+    invalid pairs marked -1; default = the MI355X kernel (metrics.part_distance_raw).  The function is backend agnostic
+    (RCCL on the GPU box, gloo in the CPU tests)."""
+    if local_fn is None:
+        from .metrics import part_distance_raw as local_fn
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    d, parts, vmax, mode = local_fn(qf, gf_local, qf_parts_visibility, gf_local_parts_visibility, dist_combine_strat, metric)
+    if mode != 0:
+        if world > 1:
+            dist.all_reduce(vmax, op=dist.ReduceOp.MAX, group=group)
+        if d.is_cuda:
+            from .metrics import fill_invalid
+            fill_invalid(d, vmax)
+            if mode == 1:
+                fill_invalid(parts, vmax)
+        else:
+            d[d == -1] = vmax + 1
+            if mode == 1:
+                parts[parts == -1] = vmax + 1
+    if world == 1:
+        return d, parts
+    sizes = torch.zeros(world, dtype=torch.int64, device=d.device)
+    sizes[dist.get_rank(group)] = d.shape[1]
+    dist.all_reduce(sizes, group=group)
+    gmax = int(sizes.max())
+    pad = torch.zeros(d.shape[0], gmax, dtype=d.dtype, device=d.device)     # all_gather needs equal shapes
+    pad[:, :d.shape[1]] = d
+    blocks = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(blocks, pad, group=group)
+    full = torch.cat([b[:, :int(n)] for b, n in zip(blocks, sizes.tolist())], dim=1)
+    return full, parts

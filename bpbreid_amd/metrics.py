@@ -21,15 +21,21 @@ def _vis_mode(qv, gv):
     return 1 if (qv.dtype is torch.bool and gv.dtype is torch.bool) else 2
 
 
-def compute_distance_matrix_using_bp_features(qf, gf, qf_parts_visibility=None, gf_parts_visibility=None,
-                                              dist_combine_strat='mean', batch_size_pairwise_dist_matrix=5000, use_gpu=True,
-                                              metric='euclidean', device=None, return_device_tensors=False):
-    """`batch_size_pairwise_dist_matrix` is accepted for signature compatibility; 288 GB of HBM holds the whole
-    [P,Q,G] result so the gallery is not chunked (results are identical: the reference's chunking only bounds memory)."""
+def _check_args(dist_combine_strat, metric):
     if dist_combine_strat not in ('mean', 'max'):
         raise ValueError('Body parts distance combination strategy "{}" not supported'.format(dist_combine_strat))
     if metric not in ('euclidean', 'cosine'):
         raise ValueError('Unknown distance metric: {}. Please choose either "euclidean" or "cosine"'.format(metric))
+
+
+def part_distance_raw(qf, gf, qf_parts_visibility=None, gf_parts_visibility=None, dist_combine_strat='mean',
+                      metric='euclidean', device=None, finalize=False):
+    """One launch of the distance kernel over (all queries) x (this gallery shard).  Returns device tensors
+    (dist [Q,G], parts [P,Q,G], vmax [1] fp32): with `finalize=False` pairs without a shared visible part are still marked
+    -1 and `vmax` holds the largest valid per-part distance of THIS shard -- a caller that shards the gallery reduces
+    `vmax` (max) over the shards and then calls `fill_invalid` (distance.py:171-176, :214-216 take the max over the whole
+    gallery)."""
+    _check_args(dist_combine_strat, metric)
     dev = device or (qf.device if qf.device.type == 'cuda' else torch.device('cuda', torch.cuda.current_device()))
     nv.init_device()
     mode = _vis_mode(qf_parts_visibility, gf_parts_visibility)
@@ -46,8 +52,24 @@ def compute_distance_matrix_using_bp_features(qf, gf, qf_parts_visibility=None, 
     gsq = torch.empty(g * p, device=dev, dtype=torch.float32)
     mx = torch.zeros(1, device=dev, dtype=torch.int32)
     nv.call('bpb_part_distance', qd.data_ptr(), gd.data_ptr(), nv.ptr(qv), nv.ptr(gv), q, g, p, d, mode, strat,
-            1 if metric == 'cosine' else 0, qsq.data_ptr(), gsq.data_ptr(), mx.data_ptr(), parts.data_ptr(), dist.data_ptr(), 1,
-            nv.stream())
+            1 if metric == 'cosine' else 0, qsq.data_ptr(), gsq.data_ptr(), mx.data_ptr(), parts.data_ptr(), dist.data_ptr(),
+            1 if finalize else 0, nv.stream())
+    return dist, parts, mx.view(torch.float32), mode
+
+
+def fill_invalid(x, vmax):
+    """-1 -> vmax + 1, in place (device tensor; `vmax` a one-element fp32 device tensor)."""
+    nv.call('bpb_part_distance_fill', x.data_ptr(), x.numel(), vmax.data_ptr(), nv.stream())
+    return x
+
+
+def compute_distance_matrix_using_bp_features(qf, gf, qf_parts_visibility=None, gf_parts_visibility=None,
+                                              dist_combine_strat='mean', batch_size_pairwise_dist_matrix=5000, use_gpu=True,
+                                              metric='euclidean', device=None, return_device_tensors=False):
+    """`batch_size_pairwise_dist_matrix` is accepted for signature compatibility; 288 GB of HBM holds the whole
+    [P,Q,G] result so the gallery is not chunked (results are identical: the reference's chunking only bounds memory)."""
+    dist, parts, _, _ = part_distance_raw(qf, gf, qf_parts_visibility, gf_parts_visibility, dist_combine_strat, metric, device,
+                                          finalize=True)
     if return_device_tensors:
         return dist, parts
     return dist.cpu(), parts.cpu()

@@ -61,15 +61,65 @@ class FusedAdam:
                 self.step_index, grad_scale, self.step_dev.data_ptr(), nv.stream())
 
     def state_dict(self):
-        return {'step': self.step_index, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq, 'lr': self.param_groups[0]['lr']}
-
-    def load_state_dict(self, sd):
+        """torch.optim.Adam's format ({'state': {i: {'step','exp_avg','exp_avg_sq'}}, 'param_groups': [...]}, positions =
+        model.parameters() order), so that checkpoints are interchangeable with the reference's (engine.py:96).  Only
+        parameters that have been updated carry state, exactly like torch."""
         self._state()
-        self.step_index = sd['step']
+        params = list(self.model.parameters())
+        state = {}
+        if self.step_index > 0:
+            for i, (p, (off, n)) in enumerate(zip(params, self.model._param_slices)):
+                if p.grad is None:
+                    continue
+                state[i] = {'step': torch.tensor(float(self.step_index)),
+                            'exp_avg': self.exp_avg[off:off + n].view_as(p).clone(),
+                            'exp_avg_sq': self.exp_avg_sq[off:off + n].view_as(p).clone()}
+        group = {'lr': self.param_groups[0]['lr'], 'betas': tuple(self.betas), 'eps': self.eps, 'weight_decay': self.weight_decay,
+                 'amsgrad': False, 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False,
+                 'fused': None, 'params': list(range(len(params)))}
+        if 'initial_lr' in self.param_groups[0]:
+            group['initial_lr'] = self.param_groups[0]['initial_lr']
+        return {'state': state, 'param_groups': [group]}
+
+    def load_state_dict(self, sd, param_names=None):
+        """Accepts torch.optim.Adam's state dict.  `param_names`: the parameter names in the order the saving optimizer saw
+        them (checkpoint.parameter_names) -- positions are matched by NAME, so a reference checkpoint loads even though this
+        model registers its sub-modules in a different order; default = this model's own order."""
+        a = self._state()
+        if 'state' not in sd:                       # flat format of earlier versions of this class
+            self.step_index = int(sd['step'])
+            self.exp_avg.copy_(sd['exp_avg'])
+            self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+            self.param_groups[0]['lr'] = sd['lr']
+            self.step_dev.fill_(self.step_index)
+            return
+        own = {name: k for k, (name, _) in enumerate(self.model.named_parameters())}
+        names = param_names if param_names is not None else list(own)
+        order = sd['param_groups'][0]['params'] if sd.get('param_groups') else list(range(len(names)))
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        steps = set()
+        params = list(self.model.parameters())
+        for pos, pid in enumerate(order):
+            st = sd['state'].get(pid)
+            if st is None:
+                continue
+            k = own[names[pos]]
+            off, n = self.model._param_slices[k]
+            assert st['exp_avg'].numel() == n, 'optimizer state of %s has the wrong size' % names[pos]
+            self.exp_avg[off:off + n].copy_(st['exp_avg'].reshape(-1))
+            self.exp_avg_sq[off:off + n].copy_(st['exp_avg_sq'].reshape(-1))
+            steps.add(int(float(st['step'])))
+        # one step counter for the whole arena (the reference's parameters all step together: unused ones never step)
+        assert len(steps) <= 1, 'parameters with different step counts are not supported: %s' % sorted(steps)
+        self.step_index = steps.pop() if steps else 0
         self.step_dev.fill_(self.step_index)
-        self.exp_avg.copy_(sd['exp_avg'])
-        self.exp_avg_sq.copy_(sd['exp_avg_sq'])
-        self.param_groups[0]['lr'] = sd['lr']
+        if sd.get('param_groups'):
+            g = sd['param_groups'][0]
+            self.param_groups[0]['lr'] = g['lr']
+            if 'initial_lr' in g:
+                self.param_groups[0]['initial_lr'] = g['initial_lr']
+            self.betas, self.eps, self.weight_decay = tuple(g.get('betas', self.betas)), g.get('eps', self.eps), g.get('weight_decay', self.weight_decay)
 
 
 class WarmupMultiStepLR:
@@ -99,4 +149,18 @@ class WarmupMultiStepLR:
 
     def step(self):
         self.last_epoch += 1
+        self._apply()
+
+    def state_dict(self):
+        """Keys of the reference scheduler's torch state dict (lr_scheduler.py:88-131 subclasses torch's _LRScheduler)."""
+        return {'milestones': list(self.milestones), 'gamma': self.gamma, 'warmup_factor': self.warmup_factor,
+                'warmup_iters': self.warmup_iters, 'warmup_method': self.warmup_method, 'base_lrs': [self.base_lr],
+                'last_epoch': self.last_epoch, '_step_count': self.last_epoch + 1, '_last_lr': [self.get_lr()]}
+
+    def load_state_dict(self, sd):
+        self.milestones = sorted(sd.get('milestones', self.milestones))
+        for k in ('gamma', 'warmup_factor', 'warmup_iters', 'warmup_method'):
+            setattr(self, k, sd.get(k, getattr(self, k)))
+        self.base_lr = sd.get('base_lrs', [self.base_lr])[0]
+        self.last_epoch = sd['last_epoch']
         self._apply()

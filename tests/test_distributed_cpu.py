@@ -60,3 +60,60 @@ def test_single_process_reducer_is_a_noop():
     red = GradAllReducer(g)
     red.start()
     assert red.finish() == 1.0 and torch.equal(g, torch.arange(10.))
+
+
+def _eval_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from bpbreid_amd.distributed import gallery_shard, sharded_part_distance
+    from oracle import metrics as OM
+    g = torch.Generator().manual_seed(4321)
+    Q, G, P, D = 9, 23, 4, 16                                  # ragged: 23 rows over 2 ranks = 12 + 11
+    qf = torch.nn.functional.normalize(torch.randn(Q, P, D, generator=g), dim=-1)
+    gf = torch.nn.functional.normalize(torch.randn(G, P, D, generator=g), dim=-1)
+    qv = torch.rand(Q, P, generator=g) < 0.7
+    gv = torch.rand(G, P, generator=g) < 0.7
+    qv[0], gv[3] = False, False
+    qv[0, 0], gv[3, 1] = True, True                            # query 0 and gallery 3 share no visible part -> filled
+
+    def local_fn(qf_, gf_, qv_, gv_, strat, metric):          # the oracle's arithmetic on one shard, fill left to the caller
+        pd = OM._part_dists(qf_, gf_, metric)
+        mask = qv_.t().unsqueeze(2) * gv_.t().unsqueeze(1)
+        valid = pd * mask + (~mask) * (-1.0)
+        d = OM._masked_mean(pd, mask) if strat == 'mean' else valid.max(0)[0]
+        return d, valid, valid.max().clamp_min(0).reshape(1).clone(), 1
+
+    out = {}
+    for strat in ('mean', 'max'):
+        b, e = gallery_shard(G, world, rank)
+        full, parts = sharded_part_distance(qf, gf[b:e], qv, gv[b:e], strat, 'euclidean', local_fn=local_fn)
+        ref_d, ref_p = OM.part_based_distance(qf, gf, qv, gv, strat)
+        assert full.shape == (Q, G) and torch.allclose(full, ref_d, atol=1e-6), strat
+        assert torch.allclose(parts, ref_p[:, :, b:e], atol=1e-6), strat
+        out[strat] = full.numpy().copy()
+    q.put((rank, out['mean'], out['max'], gallery_shard(G, world, rank)))
+    dist.destroy_process_group()
+
+
+def test_gallery_sharded_eval_distance_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert (res[0][1] == res[1][1]).all() and (res[0][2] == res[1][2]).all()      # every rank holds the same [Q,G] matrix
+    assert res[0][3] == (0, 12) and res[1][3] == (12, 23)
+
+
+def test_gallery_shard_bounds():
+    from bpbreid_amd.distributed import gallery_shard
+    for n, w in ((20000, 8), (7, 8), (23, 2), (0, 4)):
+        cuts = [gallery_shard(n, w, r) for r in range(w)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+        assert max(e - b for b, e in cuts) - min(e - b for b, e in cuts) <= 1

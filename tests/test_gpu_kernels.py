@@ -401,6 +401,32 @@ def test_part_distance_against_golden(golden_dir):
         assert np.allclose(pm.numpy(), z[key[:-8] + '/parts'], atol=3e-6), key
 
 
+def test_part_distance_gallery_shards_stitch_to_the_unsharded_result(golden_dir):
+    """The multi-GPU eval path (distributed.sharded_part_distance) on one GPU: shard kernels with the fill deferred, the
+    fill value agreed over the shards, blocks concatenated == the single launch == the reference golden."""
+    from bpbreid_amd.metrics import part_distance_raw, fill_invalid, compute_distance_matrix_using_bp_features
+    from bpbreid_amd.distributed import gallery_shard, sharded_part_distance
+    z = np.load(os.path.join(golden_dir, 'metrics.npz'))
+    qf, gf = torch.from_numpy(z['qf']), torch.from_numpy(z['gf'])
+    for vname, (qv, gv) in {'bool': (torch.from_numpy(z['qv']), torch.from_numpy(z['gv'])),
+                            'float': (torch.from_numpy(z['qvf']), torch.from_numpy(z['gvf']))}.items():
+        for strat in ('mean', 'max'):
+            full, fparts = compute_distance_matrix_using_bp_features(qf, gf, qv, gv, strat, 500, True, 'euclidean')
+            shards = []
+            for r in range(3):
+                b, e = gallery_shard(gf.shape[0], 3, r)
+                shards.append(part_distance_raw(qf, gf[b:e], qv, gv[b:e], strat, 'euclidean'))
+            vmax = torch.stack([s_[2] for s_ in shards]).max(0)[0]
+            d = torch.cat([fill_invalid(s_[0], vmax) for s_ in shards], 1).cpu()
+            assert torch.equal(d, full), (vname, strat)
+            if vname == 'bool':
+                pp = torch.cat([fill_invalid(s_[1], vmax) for s_ in shards], 2).cpu()
+                assert torch.equal(pp, fparts), (vname, strat)
+            assert np.allclose(d.numpy(), z['dist/%s/%s/euclidean/b5000/distmat' % (vname, strat)], atol=3e-6)
+            one, _ = sharded_part_distance(qf, gf, qv, gv, strat, 'euclidean')       # world size 1: same entry point
+            assert torch.equal(one.cpu(), full)
+
+
 def test_part_distance_large_ranking_identical_to_oracle():
     """Config-5 shaped check at reduced size: Q=256, G=3000, P=9, D=512 -> identical rankings (ties as sets)."""
     from bpbreid_amd.metrics import compute_distance_matrix_using_bp_features, evaluate_rank

@@ -197,3 +197,52 @@ def test_torch_optimizer_compat_path():
         opt.step()
     assert not torch.equal(before, model.pixel_classifier.classifier.weight.detach())
     assert torch.isfinite(loss)
+
+
+def test_fused_adam_state_interchanges_with_torch_adam(tmp_path):
+    """FusedAdam exports / imports torch.optim.Adam's state-dict format (checkpoint compatibility): after two
+    fused steps, a torch.optim.Adam loaded with the exported state takes the same third step; and a state whose positions
+    follow a different parameter order loads through the names."""
+    from bpbreid_amd import checkpoint as ck
+    cfg = Cm.make_cfg('hrnet_w8', 3, 32)
+    imgs, masks, pids = Cm.synth_batch(8, 64, 32, 3, 8)
+    data = {'image': imgs, 'mask': masks, 'pid': pids}
+
+    def fresh():
+        m = Cm.fill_state_dict_(bpbreid(8, config=cfg, pretrained=False)).to(DEV)
+        return m, ImagePartBasedEngine(m, optimizer=FusedAdam(m, lr=1e-3, weight_decay=5e-4), losses_weights=WEIGHTS_DEFAULT)
+
+    m1, e1 = fresh()
+    for _ in range(2):
+        e1.forward_backward(data)
+    sd = e1.optimizer.state_dict()
+    assert set(sd) == {'state', 'param_groups'} and sd['param_groups'][0]['lr'] == 1e-3
+    stepped = [i for i, p in enumerate(m1.parameters()) if p.grad is not None]
+    assert sorted(sd['state']) == stepped and float(sd['state'][stepped[0]]['step']) == 2.0
+    path = ck.save_checkpoint({'state_dict': m1.state_dict(), 'epoch': 2, 'optimizer': sd}, str(tmp_path), job_id=0)
+    # (a) into torch.optim.Adam on a second model
+    m2, e2 = fresh()
+    topt = torch.optim.Adam(list(m2.parameters()), lr=1e-3, weight_decay=5e-4)
+    assert ck.resume_from_checkpoint(path, m2, topt) == 2
+    e2.optimizer = topt
+    e1.forward_backward(data)
+    e2.forward_backward(data)
+    for (n, a), b in zip(m1.named_parameters(), m2.parameters()):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), n
+    # (b) back into FusedAdam through parameter NAMES, with the saving side's positions permuted
+    names = [n for n, _ in m1.named_parameters()]
+    perm = list(reversed(range(len(names))))
+    shuffled = {'state': {pos: sd['state'][i] for pos, i in enumerate(perm) if i in sd['state']},
+                'param_groups': [dict(sd['param_groups'][0], params=list(range(len(names))))]}
+    m3, e3 = fresh()
+    m3.load_state_dict(ck.load_checkpoint(path)['state_dict'])
+    e3.optimizer.load_state_dict(shuffled, param_names=[names[i] for i in perm])
+    assert e3.optimizer.step_index == 2
+    m4, e4 = fresh()
+    assert ck.resume_from_checkpoint(path, m4, e4.optimizer) == 2
+    e3.forward_backward(data)
+    e4.forward_backward(data)
+    for (n, a), b in zip(m3.named_parameters(), m4.parameters()):
+        assert torch.equal(a, b), n
+    for (n, a), b in zip(m1.named_parameters(), m4.parameters()):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), n
