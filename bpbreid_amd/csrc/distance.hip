@@ -107,6 +107,185 @@ __global__ __launch_bounds__(256) void bpb_part_distance_kernel(const float* __r
     if (lane == 0 && lmax > 0.f) atomicMax(maxbits, __float_as_int(lmax));
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Tiled variant (D % 32 == 0, operands < 2 GiB): 128 (query) x 128 (gallery) outputs per workgroup, 4 waves of 64 x 64
+// (four 32x32 accumulators each), 32-wide K chunks streamed global -> LDS by `buffer_load ... lds` DMA into a double buffer
+// (one barrier per chunk, out-of-range rows zero-filled by the descriptor), operands read as 16-byte fragments with the
+// same channel permutation as the convolution kernel ([row][8 data + 1 pad slots]: conflict-free).  Each part's distance
+// is folded into ONE register array (masked sum or masked max); the pair weights sum_p m_p are recomputed from the
+// visibility vectors at the end instead of being carried through the P loop.  Arithmetic per element is identical to the
+// 64x64 kernel above (same fp32 operation order) -- the MFMA k-order differs (8-channel groups), which is round-off only.
+template <int STRAT>
+__global__ __launch_bounds__(256) void bpb_part_distance_tiled_kernel(const float* __restrict__ qf, const float* __restrict__ gf,
+                                                                        const float* __restrict__ qsq, const float* __restrict__ gsq,
+                                                                        const float* __restrict__ qvis, const float* __restrict__ gvis,
+                                                                        int Q, int G, int P, int D, int mode, int cosine,
+                                                                        float* __restrict__ parts_out, float* __restrict__ dist_out,
+                                                                        int* __restrict__ maxbits, unsigned q_bytes, unsigned g_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int SLOTS = 1280;                       // 128 rows x 9 slots = 1152, padded to 5 x 256 DMA pieces
+    constexpr unsigned OOB = 0x80000000u;
+    const int tiles_g = (G + 127) >> 7;
+    const int tq = blockIdx.x / tiles_g, tg = blockIdx.x % tiles_g;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wq = wave >> 1, wg = wave & 1;
+    const int q0 = tq * 128, g0 = tg * 128;
+    const long PD = (long)P * D;
+
+    __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)qf, 0, (int)q_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)gf, 0, (int)g_bytes, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    unsigned aofs[5], bofs[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int idx = k * 256 + (int)threadIdx.x;
+        const int row = idx / 9, v = idx - row * 9;
+        const bool ok = idx < 1152 && v < 8;
+        aofs[k] = (ok && q0 + row < Q) ? (unsigned)(((long)(q0 + row) * PD + v * 4) * 4) : OOB;
+        bofs[k] = (ok && g0 + row < G) ? (unsigned)(((long)(g0 + row) * PD + v * 4) * 4) : OOB;
+    }
+    auto dma_issue = [&](int p, int k0, int buf) {
+        const unsigned inc = (unsigned)((p * D + k0) * 4);
+        char* base = (char*)smem + buf * (2 * SLOTS * 16) + wave * 1024;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_ptr_t)(base + k * 4096), 16, (int)(aofs[k] + inc), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_ptr_t)(base + SLOTS * 16 + k * 4096), 16, (int)(bofs[k] + inc), 0, 0, 0);
+        }
+    };
+    const int a_lane = ((wq * 64 + l31) * 9 + half) * 16;          // byte offset of this lane's A fragment (mt = 0, kg = 0)
+    const int b_lane = SLOTS * 16 + ((wg * 64 + l31) * 9 + half) * 16;
+
+    f32x16 comb[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) comb[mt][nt][r] = STRAT == 1 ? -1.f : 0.f;
+    float lmax = 0.f;
+    const int nch = D >> 5;
+    const int nwork = P * nch;
+    dma_issue(0, 0, 0);
+    f32x16 acc[2][2];
+    int p = 0, ch = 0;
+    for (int w = 0; w < nwork; ++w) {
+        __syncthreads();                                   // chunk w has landed; the other buffer is free
+        if (w + 1 < nwork) {
+            const bool lastc = ch + 1 == nch;
+            dma_issue(lastc ? p + 1 : p, lastc ? 0 : (ch + 1) * 32, (w + 1) & 1);
+        }
+        if (ch == 0) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+        }
+        const char* sb = (const char*)smem + (w & 1) * (2 * SLOTS * 16);
+        f32x4 a[2][2], b[2][2];                             // [ping-pong][sub-tile]
+        auto fetch = [&](int kg, f32x4 (&af)[2], f32x4 (&bf)[2]) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                af[t] = *(const f32x4*)(sb + a_lane + t * (32 * 9 * 16) + kg * 32);
+                bf[t] = *(const f32x4*)(sb + b_lane + t * (32 * 9 * 16) + kg * 32);
+            }
+        };
+        auto mma = [&](const f32x4 (&af)[2], const f32x4 (&bf)[2]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = MFMA32(af[mt][i], bf[nt][i], acc[mt][nt]);
+        };
+        fetch(0, a[0], b[0]);
+        fetch(1, a[1], b[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a[0], b[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(2, a[0], b[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a[1], b[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(3, a[1], b[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a[0], b[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a[1], b[1]);
+        if (++ch == nch) {                                  // ---- this part is complete: distances, mask, fold
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int g = g0 + wg * 64 + nt * 32 + l31;
+                const bool gok = g < G;
+                const float gs = gok ? gsq[(long)g * P + p] : 0.f;
+                const float gv = (mode != 0 && gok) ? gvis[(long)g * P + p] : 1.f;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int q = q0 + wq * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (q < Q && gok) {
+                            float d;
+                            if (cosine) d = 1.f - acc[mt][nt][r];
+                            else {
+                                d = qsq[(long)q * P + p] - 2.f * acc[mt][nt][r] + gs;
+                                d = sqrtf(d > 0.f ? d : 0.f);
+                            }
+                            float m = 1.f;
+                            if (mode != 0) {
+                                m = qvis[(long)q * P + p] * gv;
+                                if (mode == 2) m = sqrtf(m);
+                            }
+                            float pv = d;
+                            if (mode == 1 && m == 0.f) pv = -1.f;
+                            parts_out[((long)p * Q + q) * G + g] = pv;
+                            if (pv > lmax) lmax = pv;
+                            if (STRAT == 1) { if (m != 0.f && d > comb[mt][nt][r]) comb[mt][nt][r] = d; }
+                            else comb[mt][nt][r] += d * m;
+                        }
+                    }
+                }
+            }
+            ch = 0;
+            ++p;
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int g = g0 + wg * 64 + nt * 32 + l31;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = q0 + wq * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (q < Q && g < G) {
+                    float v;
+                    if (STRAT == 1) v = comb[mt][nt][r];                       // stays -1 when no part is shared
+                    else if (mode == 0) v = comb[mt][nt][r] / (float)P;
+                    else {
+                        float sw = 0.f;                                         // sum_p m_p, same order as the P loop
+                        for (int pp = 0; pp < P; ++pp) {
+                            float m = qvis[(long)q * P + pp] * gvis[(long)g * P + pp];
+                            if (mode == 2) m = sqrtf(m);
+                            sw += m;
+                        }
+                        v = sw == 0.f ? -1.f : comb[mt][nt][r] / sw;
+                    }
+                    dist_out[(long)q * G + g] = v;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+    if (lane == 0 && lmax > 0.f) atomicMax(maxbits, __float_as_int(lmax));
+}
+
 // -1 -> max + 1  (distance.py:171-176 for boolean masks: both matrices; :214-216 for continuous: distmat only)
 __global__ __launch_bounds__(256) void bpb_fill_invalid_kernel(float* __restrict__ x, long n, const int* __restrict__ maxbits)
 {
@@ -130,9 +309,27 @@ int bpb_part_distance(const float* qf, const float* gf, const float* qvis, const
     (void)hipMemsetAsync(maxbits, 0, sizeof(int), stream);
     hipLaunchKernelGGL(bpb_rownorm_kernel, dim3(bpb_cdiv((long)Q * P, 4)), dim3(256), 0, stream, qf, qsq, (long)Q * P, D);
     hipLaunchKernelGGL(bpb_rownorm_kernel, dim3(bpb_cdiv((long)G * P, 4)), dim3(256), 0, stream, gf, gsq, (long)G * P, D);
-    const int tiles = bpb_cdiv(Q, 64) * bpb_cdiv(G, 64);
-    hipLaunchKernelGGL(bpb_part_distance_kernel, dim3(tiles), dim3(256), 0, stream, qf, gf, qsq, gsq, qvis, gvis, Q, G, P, D,
-                       mode, strat, cosine, parts_out, dist_out, maxbits);
+    const double qb = (double)Q * P * D * 4.0, gb = (double)G * P * D * 4.0;
+    if (D % 32 == 0 && qb < 2147483648.0 && gb < 2147483648.0 && (Q >= 128 || G >= 128)) {
+        static bool attr_done = false;
+        const int lds = 2 * 2 * 1280 * 16;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)bpb_part_distance_tiled_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)hipFuncSetAttribute((const void*)bpb_part_distance_tiled_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            attr_done = true;
+        }
+        const int tiles = bpb_cdiv(Q, 128) * bpb_cdiv(G, 128);
+        if (strat == 1)
+            hipLaunchKernelGGL(bpb_part_distance_tiled_kernel<1>, dim3(tiles), dim3(256), lds, stream, qf, gf, qsq, gsq, qvis, gvis,
+                               Q, G, P, D, mode, cosine, parts_out, dist_out, maxbits, (unsigned)qb, (unsigned)gb);
+        else
+            hipLaunchKernelGGL(bpb_part_distance_tiled_kernel<0>, dim3(tiles), dim3(256), lds, stream, qf, gf, qsq, gsq, qvis, gvis,
+                               Q, G, P, D, mode, cosine, parts_out, dist_out, maxbits, (unsigned)qb, (unsigned)gb);
+    } else {
+        const int tiles = bpb_cdiv(Q, 64) * bpb_cdiv(G, 64);
+        hipLaunchKernelGGL(bpb_part_distance_kernel, dim3(tiles), dim3(256), 0, stream, qf, gf, qsq, gsq, qvis, gvis, Q, G, P, D,
+                           mode, strat, cosine, parts_out, dist_out, maxbits);
+    }
     if (finalize && mode != 0) {
         hipLaunchKernelGGL(bpb_fill_invalid_kernel, dim3(1024), dim3(256), 0, stream, dist_out, (long)Q * G, maxbits);
         if (mode == 1)

@@ -1,0 +1,53 @@
+"""GPU: eval-path measurement at BASELINE config-5 size (Q=2048, G=20000, P=9, D=512, bool visibility ~ Bernoulli(0.8),
+SURVEY.md 8d): part-based distance kernel (2*P*Q*G*D FLOP, [P,Q,G] fp32 written once) and the native CMC/mAP evaluator,
+plus size-independent checks (symmetry of the self-distance, zero diagonal, ranking of an exact duplicate)."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT]
+import numpy as np                                            # noqa: E402
+import torch                                                  # noqa: E402
+import torch.nn.functional as F                               # noqa: E402
+from bpbreid_amd.metrics import compute_distance_matrix_using_bp_features, evaluate_rank   # noqa: E402
+
+Q, G, P, D = [int(a) for a in (sys.argv[1:5] if len(sys.argv) > 4 else (2048, 20000, 9, 512))]
+dev = torch.device('cuda', 0)
+g = torch.Generator().manual_seed(4321)
+qf = F.normalize(torch.randn(Q, P, D, generator=g), dim=-1).to(dev)
+gf = F.normalize(torch.randn(G, P, D, generator=g), dim=-1).to(dev)
+qv = (torch.rand(Q, P, generator=g) < 0.8)
+gv = (torch.rand(G, P, generator=g) < 0.8)
+qv[:, 0], gv[:, 0] = True, True
+gf[17] = qf[5]                                              # an exact duplicate: must rank first for query 5
+gv[17] = qv[5]
+qv, gv = qv.to(dev), gv.to(dev)
+q_pids = torch.randint(0, 1500, (Q,), generator=g).numpy()
+g_pids = torch.randint(0, 1500, (G,), generator=g).numpy()
+q_cam = torch.randint(0, 6, (Q,), generator=g).numpy()
+g_cam = torch.randint(0, 6, (G,), generator=g).numpy()
+for _ in range(2):
+    dm, pm = compute_distance_matrix_using_bp_features(qf, gf, qv, gv, 'mean', 500, True, 'euclidean', return_device_tensors=True)
+torch.cuda.synchronize()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+reps = 5
+for _ in range(reps):
+    dm, pm = compute_distance_matrix_using_bp_features(qf, gf, qv, gv, 'mean', 500, True, 'euclidean', return_device_tensors=True)
+e.record()
+torch.cuda.synchronize()
+ms = s.elapsed_time(e) / reps
+flops = 2.0 * P * Q * G * D
+out_bytes = 4.0 * (P + 1) * Q * G
+dmc = dm.cpu().numpy()
+assert int(np.argmin(dmc[5])) == 17 and dmc[5, 17] < 1e-3
+self_d, _ = compute_distance_matrix_using_bp_features(qf[:512], qf[:512], qv[:512], qv[:512], 'mean', 500, True, 'euclidean')
+assert float(self_d.diag().abs().max()) < 1e-3 and float((self_d - self_d.t()).abs().max()) < 1e-5
+t0 = time.perf_counter()
+res = evaluate_rank(dmc, q_pids, g_pids, q_cam, g_cam, max_rank=50)
+t_rank = time.perf_counter() - t0
+print(json.dumps({'Q': Q, 'G': G, 'P': P, 'D': D, 'distance_ms': ms, 'distance_tflops': flops / ms * 1e-9,
+                  'distance_frac_of_f32_mfma_peak': flops / ms * 1e-9 / 157.3, 'output_GBps': out_bytes / ms * 1e-6,
+                  'rank_seconds': t_rank, 'rank_queries_per_s': Q / t_rank, 'mAP': res['mAP'], 'rank1': float(res['cmc'][0])}))
