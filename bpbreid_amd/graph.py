@@ -237,7 +237,12 @@ class Net:
             blocks = (-(-n // ti_)) * (-(-a // th_)) * (-(-b // tw_)) * (-(-cout // ((32 * nt) << lwn)))
             scored.append((blocks, pixels * ((32 * nt) << lwn), mt_r, lwn, nt, ti_, th_, tw_))
         ok = [s_ for s_ in scored if s_[0] >= 384]
-        best = max(ok, key=lambda s_: (s_[1], s_[0])) if ok else max(scored, key=lambda s_: (s_[0], s_[1]))
+        best = max(ok, key=lambda s_: (s_[1], s_[4], s_[0])) if ok else max(scored, key=lambda s_: (s_[0], s_[1]))
+        # stride-2 gathers carry a 4x larger halo per output pixel: the 64-pixel x 64-channel shape (two waves along the
+        # channels) wins on every strided HRNet conv (tools/conv_sweep.py: 151 -> 130 us on 64->64 @128x64)
+        strided = [s_ for s_ in scored if (s_[2], s_[3], s_[4]) == (1, 1, 1)]
+        if sa == 2 and strided and forced is None:
+            best = strided[0]
         _, _, mt_r, lwn, nt, ti, th, tw = best
         hh = (th - 1) * sa + span_h + 1
         hw = (tw - 1) * sa + span_w + 1
@@ -260,8 +265,11 @@ class Net:
         ld_of = lambda c_: 4 if cin == 4 else c_ + 4
         dma = 1 if getattr(self, 'use_dma', True) else 0
         choice = None
+        n_blocks = best[0]
         if dma:
-            for limit in (78 * 1024, 160 * 1024):
+            # two workgroups per CU only matter when the launch has more than one workgroup per CU to begin with; a launch
+            # of <= 256 workgroups takes the largest chunk that fits (fewer barriers: 65 -> 54 us on 256->256 @8x4)
+            for limit in ((160 * 1024,) if n_blocks <= 256 else (78 * 1024, 160 * 1024)):
                 fit = [c_ for c_ in cks if lds_bytes(c_, ld_of(c_), 2) <= limit]
                 if fit:
                     choice = (fit[0], 1)
