@@ -352,6 +352,16 @@ __global__ __launch_bounds__(256) void bpb_term_bwd_bn_apply_kernel(BpbTermBwdAr
             for (int e = 0; e < 4; ++e) d[e] += old[e];
         }
         *(f32x4*)o = d;
+        if (A.dsrc2) {   // the identity (skip) term of the same fuse op, same resolution (up == 0): dsrc2 (+)= G
+            float* o2 = A.dsrc2 + q * A.C + cq * 4;
+            f32x4 g2 = g;
+            if (A.accumulate2) {
+                const f32x4 old2 = *(const f32x4*)o2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g2[e] += old2[e];
+            }
+            *(f32x4*)o2 = g2;
+        }
     }
 }
 

@@ -121,6 +121,7 @@ class Net:
         self.multi_tile = os.environ.get('BPB_MULTI_TILE', '0') == '1'
         self.wgrad_streams = os.environ.get('BPB_WGRAD_STREAMS', '1') != '0'
         self.interleave = os.environ.get('BPB_INTERLEAVE', '1') != '0'
+        self.merge_identity = os.environ.get('BPB_MERGE_IDENTITY', '1') != '0'
         self._side_used = set()
 
     # ------------------------------------------------------------------ graph construction
@@ -527,7 +528,10 @@ class Net:
             elif kind == 'fuse':
                 out, terms, relu = pay
                 gout = out.ensure_grad(self)
-                for t, up in terms:
+                merged = set()       # identity terms whose gradient is written by a BN term's apply pass
+                for k_term, (t, up) in enumerate(terms):
+                    if k_term in merged:
+                        continue
                     ta = TermBwdArgs()
                     a = t.y if isinstance(t, ConvNode) else t
                     ta.dout = gout.data_ptr()
@@ -548,6 +552,15 @@ class Net:
                         ta.dsrc = a.ensure_grad(self).data_ptr()
                         ta.partials = part.data_ptr()
                         ta.accumulate = a.take_acc_flag()
+                        ta.dsrc2, ta.accumulate2, extra = None, 0, 0.0
+                        if up == 0 and self.merge_identity:
+                            for k2, (t2, up2) in enumerate(terms):
+                                if k2 not in merged and not isinstance(t2, ConvNode) and up2 == 0 and t2.needs_grad:
+                                    ta.dsrc2 = t2.ensure_grad(self).data_ptr()
+                                    ta.accumulate2 = t2.take_acc_flag()
+                                    merged.add(k2)
+                                    extra = 4.0 * t2.buf.numel()
+                                    break
                         win = 4 ** up
                         eb = 4.0 * a.buf.numel()
                         bwd.add(self._op(nv.OP_TERM_BWD, ints=(1, nblocks), ptrs=(C.addressof(ta),)), 'bn_bwd_reduce', 0,
@@ -555,7 +568,7 @@ class Net:
                         bwd.add(self._op(nv.OP_BN_BWD_FINALIZE, ints=(nblocks, a.C, 0), doubles=(float(npix),),
                                          ptrs=(part, bn.weight.grad, bn.bias.grad, bn.c1, bn.c2)), 'bn_bwd_finalize')
                         bwd.add(self._op(nv.OP_TERM_BWD, ints=(2, 0), ptrs=(C.addressof(ta),)), 'bn_bwd_apply', 0,
-                                eb * (2 + 2 * win))
+                                eb * (2 + 2 * win) + extra)
                     else:
                         if not a.needs_grad:
                             continue

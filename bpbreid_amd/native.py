@@ -48,7 +48,8 @@ class TermBwdArgs(C.Structure):
     _fields_ = [('dout', c_fp), ('out', c_fp), ('src', c_fp), ('mean', c_fp), ('invstd', c_fp), ('scale', c_fp),
                 ('c1', c_fp), ('c2', c_fp), ('dsrc', c_fp), ('partials', c_fp),
                 ('N', C.c_int), ('Hs', C.c_int), ('Ws', C.c_int), ('C', C.c_int), ('up', C.c_int),
-                ('relu', C.c_int), ('accumulate', C.c_int), ('magic_w', C.c_uint), ('magic_h', C.c_uint)]
+                ('relu', C.c_int), ('accumulate', C.c_int), ('magic_w', C.c_uint), ('magic_h', C.c_uint),
+                ('dsrc2', c_fp), ('accumulate2', C.c_int)]
 
 
 class BilinearArgs(C.Structure):

@@ -122,6 +122,8 @@ typedef struct BpbTermBwdArgs {
     int N, Hs, Ws, C, up;   // src spatial dims; out dims are Hs<<up, Ws<<up
     int relu, accumulate;
     unsigned magic_w, magic_h;   // for Ws, Hs
+    float* dsrc2;           // BN apply only, optional: an identity term of the same fuse op at the same resolution
+    int accumulate2;        //   (the residual skip): dsrc2 (+)= G is written by the same pass (one launch, dout/out read once)
 } BpbTermBwdArgs;
 
 /* bilinear (align_corners) upsample of one map into a channel slice of the concatenated map */
