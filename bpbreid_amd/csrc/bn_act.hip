@@ -286,9 +286,56 @@ __global__ __launch_bounds__(256) void bpb_term_bwd_bn_reduce_kernel(BpbTermBwdA
         if (trow == 0) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                A.partials[((size_t)blockIdx.x * 2 + 0) * A.C + cq * 4 + e] = ds[e];
-                A.partials[((size_t)blockIdx.x * 2 + 1) * A.C + cq * 4 + e] = dsx[e];
+                // write-through (sc1) stores: see the hand-off at the end of the kernel
+                __hip_atomic_store(&A.partials[((size_t)blockIdx.x * 2 + 0) * A.C + cq * 4 + e], ds[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&A.partials[((size_t)blockIdx.x * 2 + 1) * A.C + cq * 4 + e], dsx[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+        }
+    }
+    // ---- fused finalisation (see bpb_conv_igemm_kernel): the last workgroup to finish turns the partials into
+    // dgamma / dbeta and the per-channel constants c1, c2 of the apply pass -- no separate 2-8 workgroup launch in between.
+    if (A.counter) {
+        // hand-off without fences: sc1 partial stores, every wave drains, one relaxed agent-scope ticket, ONE acquire + plain loads
+        // in the last arriver (a __threadfence() here writes back / invalidates the L2 once per workgroup: measured 70 % slower)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) red[0] = (double)__hip_atomic_fetch_add(A.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int ticket = (int)red[0];
+        if (ticket == (int)gridDim.x - 1) {
+            if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // ONE acquire, then plain pipelined loads
+            __syncthreads();
+            const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+            const int nparts = (int)gridDim.x;
+            for (int cb = 0; cb < A.C; cb += 32) {
+                const int c = cb + cl;
+                double s0 = 0.0, s1 = 0.0;
+                if (c < A.C)
+#pragma unroll 8
+                    for (int p = rl; p < nparts; p += 8) {
+                        s0 += A.partials[((size_t)p * 2 + 0) * A.C + c];
+                        s1 += A.partials[((size_t)p * 2 + 1) * A.C + c];
+                    }
+                __syncthreads();
+                red[(0 * 8 + rl) * 32 + cl] = s0;
+                red[(1 * 8 + rl) * 32 + cl] = s1;
+                __syncthreads();
+                if (rl == 0 && c < A.C) {
+                    s0 = 0.0;
+                    s1 = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        s0 += red[(0 * 8 + i) * 32 + cl];
+                        s1 += red[(1 * 8 + i) * 32 + cl];
+                    }
+                    if (A.dbeta) A.dbeta[c] = A.acc_param ? A.dbeta[c] + (float)s0 : (float)s0;
+                    if (A.dgamma) A.dgamma[c] = A.acc_param ? A.dgamma[c] + (float)s1 : (float)s1;
+                    ((float*)A.c1)[c] = (float)(s0 / A.count);
+                    ((float*)A.c2)[c] = (float)(s1 / A.count);
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_store(A.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

@@ -315,9 +315,10 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_igemm_kernel(const BpbConvPro
                         s += red[((w * NT + nt) * 32 + c) * 2 + 0];
                         q += red[((w * NT + nt) * 32 + c) * 2 + 1];
                     }
-                    double BPB_GLOBAL* gs = (double BPB_GLOBAL*)P.stats;
-                    gs[((size_t)mtile * 2 + 0) * Cout + co] = s;
-                    gs[((size_t)mtile * 2 + 1) * Cout + co] = q;
+                    // write-through (sc1) stores: visible to the finalising workgroup on any XCD without a release fence
+                    double* gs = (double*)P.stats;
+                    __hip_atomic_store(&gs[((size_t)mtile * 2 + 0) * Cout + co], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&gs[((size_t)mtile * 2 + 1) * Cout + co], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
@@ -418,6 +419,72 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_igemm_kernel(const BpbConvPro
             epilogue(mtile);
             chunk = 0;
             ++mtile;
+        }
+    }
+
+    // ---- fused BatchNorm finalisation: the last workgroup of this problem to get here reduces the partials of ALL tiles
+    // (fixed order: 8 row lanes per channel, lanes combined 0..7 -> deterministic) and writes scale / shift / saved
+    // statistics / running statistics.  It is already resident, so unlike a separate tiny launch it never queues behind
+    // the big kernels of the other streams for a CU.
+    if (P.stats && P.bnf) {
+        const BpbBnFinalizeArgs F = *P.bnf;
+        // Hand-off (cdna_hip_programming.md, Guideline 16, write-through form): the partials were stored sc1, every wave
+        // drains its stores, then ONE lane takes a relaxed agent-scope ticket; the last arriver issues ONE agent-scope
+        // acquire and reads the partials with plain loads.  No __threadfence(): a whole-L2 write-back per workgroup made the step 70 % slower.
+        volatile int* s_ticket = (volatile int*)((char*)smem + redbase);   // (dynamic LDS: no static allocation in this kernel)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0)
+            *s_ticket = __hip_atomic_fetch_add(F.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int ticket = *s_ticket;
+        __syncthreads();                       // everyone has read the ticket before the scratch is reused below
+        const int nblk = ((P.n_mtiles + P.tpb - 1) / P.tpb) * P.n_ntiles;
+        if (ticket == nblk - 1) {
+            if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // ONE acquire, then plain pipelined loads
+            __syncthreads();
+            double* red = (double*)((char*)smem + redbase);        // [2][8][32] doubles = the 4 KiB scratch
+            const double BPB_GLOBAL* gs = (const double BPB_GLOBAL*)P.stats;
+            const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+            for (int cb = 0; cb < Cout; cb += 32) {
+                const int c = cb + cl;
+                double sm = 0.0, sq = 0.0;
+                if (c < Cout)
+#pragma unroll 8
+                    for (int row = rl; row < P.n_mtiles; row += 8) {
+                        sm += gs[((size_t)row * 2 + 0) * Cout + c];
+                        sq += gs[((size_t)row * 2 + 1) * Cout + c];
+                    }
+                red[(0 * 8 + rl) * 32 + cl] = sm;
+                red[(1 * 8 + rl) * 32 + cl] = sq;
+                __syncthreads();
+                if (rl == 0 && c < Cout) {
+                    sm = 0.0;
+                    sq = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        sm += red[(0 * 8 + i) * 32 + cl];
+                        sq += red[(1 * 8 + i) * 32 + cl];
+                    }
+                    const double mean = sm / F.count;
+                    double var = sq / F.count - mean * mean;
+                    if (var < 0.0) var = 0.0;
+                    const float invstd = (float)(1.0 / sqrt(var + (double)F.eps));
+                    const float g = F.gamma ? F.gamma[c] : 1.f, b = F.beta ? F.beta[c] : 0.f;
+                    const float sc = g * invstd;
+                    F.scale[c] = sc;
+                    F.shift[c] = b - (float)mean * sc;
+                    F.mean[c] = (float)mean;
+                    F.invstd[c] = invstd;
+                    if (F.running_mean) {
+                        const double unbiased = F.count > 1.0 ? var * F.count / (F.count - 1.0) : var;
+                        F.running_mean[c] = (1.f - F.momentum) * F.running_mean[c] + F.momentum * (float)mean;
+                        F.running_var[c] = (1.f - F.momentum) * F.running_var[c] + F.momentum * (float)unbiased;
+                    }
+                }
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) __hip_atomic_store(F.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
         }
     }
 }

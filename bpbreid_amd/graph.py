@@ -17,7 +17,7 @@ import os
 import torch
 
 from . import native as nv
-from .native import ConvProb, WgradProb, PackProb, FuseArgs, TermBwdArgs, BilinearArgs, PlanOp, magic, ptr
+from .native import ConvProb, WgradProb, PackProb, FuseArgs, TermBwdArgs, BilinearArgs, BnFinalizeArgs, PlanOp, magic, ptr
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -122,6 +122,10 @@ class Net:
         self.wgrad_streams = os.environ.get('BPB_WGRAD_STREAMS', '1') != '0'
         self.interleave = os.environ.get('BPB_INTERLEAVE', '1') != '0'
         self.merge_identity = os.environ.get('BPB_MERGE_IDENTITY', '1') != '0'
+        # BatchNorm finalisation by the last workgroup of the producing launch: implemented, tested (bit-reproducible), but
+        # measured 2-3 % slower than the separate 2-8 workgroup launches (serial tail of the last workgroup) -> opt-in
+        self.fuse_finalize = os.environ.get('BPB_FUSE_FINALIZE', '0') == '1'
+        self._counters = None
         self._side_used = set()
 
     # ------------------------------------------------------------------ graph construction
@@ -208,6 +212,15 @@ class Net:
             else:
                 op.p[k] = v
         return op
+
+    def _new_counter(self):
+        """Address of a zeroed int32 in device memory (ticket counter of a fused finalisation; reset by its last user)."""
+        if self._counters is None or self._counters[1] >= self._counters[0].numel():
+            self._counters = [torch.zeros(4096, device=self.device, dtype=torch.int32), 0]
+            self.keep.append(self._counters[0])
+        addr = self._counters[0].data_ptr() + 4 * self._counters[1]
+        self._counters[1] += 1
+        return addr
 
     def _dev_struct(self, st):
         """Copy a ctypes struct (array) to device memory; returns (device tensor, host object)."""
@@ -390,15 +403,34 @@ class Net:
                 prob = self.conv_problem(x.buf, (x.N, x.H, x.W), cv.wf, y.buf, (y.H, y.W), y.H, y.W, (1, 1, 0, 0),
                                          cv.stride, (-cv.pad, -cv.pad), (cv.R, cv.S, 0, 1, 0, 1, 0, cv.S, 1), x.C, y.C,
                                          bias=cv.bias, stats=stats)
-                self._emit_conv(both, prob, 'conv_fwd')
-                if cv.bn is not None:
+                if cv.bn is None:
+                    self._emit_conv(both, prob, 'conv_fwd')
+                else:
                     bn = cv.bn
                     cv.stats_buf = stats[0]
                     count = float(y.N * y.H * y.W)
-                    self.fwd_train.add(self._op(
-                        nv.OP_BN_FINALIZE, ints=(prob.n_mtiles, y.C), floats=(BN_EPS, BN_MOMENTUM), doubles=(count,),
-                        ptrs=(cv.stats_buf, bn.weight, bn.bias, bn.scale, bn.shift, bn.mean, bn.invstd, bn.running_mean,
-                              bn.running_var)), 'bn_finalize')
+                    # eval plan: same launch without the statistics epilogue, affine from the running statistics
+                    prob_eval = ConvProb.from_buffer_copy(prob)
+                    prob_eval.stats = None
+                    prob_eval.bnf = None
+                    self.keep.append(prob_eval)
+                    if self.fuse_finalize:
+                        # train plan: the conv launch finalises its own BatchNorm statistics (last workgroup), no extra launch
+                        bnf = BnFinalizeArgs()
+                        bnf.gamma, bnf.beta = bn.weight.data_ptr(), bn.bias.data_ptr()
+                        bnf.scale, bnf.shift = bn.scale.data_ptr(), bn.shift.data_ptr()
+                        bnf.mean, bnf.invstd = bn.mean.data_ptr(), bn.invstd.data_ptr()
+                        bnf.running_mean, bnf.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                        bnf.counter = self._new_counter()
+                        bnf.count, bnf.eps, bnf.momentum = count, BN_EPS, BN_MOMENTUM
+                        prob.bnf = self._dev_struct(bnf).data_ptr()
+                    self._emit_conv([self.fwd_train], prob, 'conv_fwd')
+                    self._emit_conv([self.fwd_eval], prob_eval, 'conv_fwd')
+                    if not self.fuse_finalize:
+                        self.fwd_train.add(self._op(
+                            nv.OP_BN_FINALIZE, ints=(prob.n_mtiles, y.C), floats=(BN_EPS, BN_MOMENTUM), doubles=(count,),
+                            ptrs=(cv.stats_buf, bn.weight, bn.bias, bn.scale, bn.shift, bn.mean, bn.invstd, bn.running_mean,
+                                  bn.running_var)), 'bn_finalize')
                     self.fwd_eval.add(self._op(
                         nv.OP_BN_EVAL_AFFINE, ints=(y.C,), floats=(BN_EPS,),
                         ptrs=(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.scale, bn.shift)), 'bn_eval_affine')
@@ -563,10 +595,14 @@ class Net:
                                     break
                         win = 4 ** up
                         eb = 4.0 * a.buf.numel()
+                        if self.fuse_finalize:     # the reduce launch finalises dgamma / dbeta / c1 / c2 itself (last workgroup)
+                            ta.dgamma, ta.dbeta = bn.weight.grad.data_ptr(), bn.bias.grad.data_ptr()
+                            ta.counter, ta.count, ta.acc_param = self._new_counter(), float(npix), 0
                         bwd.add(self._op(nv.OP_TERM_BWD, ints=(1, nblocks), ptrs=(C.addressof(ta),)), 'bn_bwd_reduce', 0,
                                 eb * (1 + 2 * win))
-                        bwd.add(self._op(nv.OP_BN_BWD_FINALIZE, ints=(nblocks, a.C, 0), doubles=(float(npix),),
-                                         ptrs=(part, bn.weight.grad, bn.bias.grad, bn.c1, bn.c2)), 'bn_bwd_finalize')
+                        if not self.fuse_finalize:
+                            bwd.add(self._op(nv.OP_BN_BWD_FINALIZE, ints=(nblocks, a.C, 0), doubles=(float(npix),),
+                                             ptrs=(part, bn.weight.grad, bn.bias.grad, bn.c1, bn.c2)), 'bn_bwd_finalize')
                         bwd.add(self._op(nv.OP_TERM_BWD, ints=(2, 0), ptrs=(C.addressof(ta),)), 'bn_bwd_apply', 0,
                                 eb * (2 + 2 * win) + extra)
                     else:

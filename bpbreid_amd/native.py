@@ -22,7 +22,13 @@ class ConvProb(C.Structure):
             'Rt', 'St', 'dh0', 'dhs', 'dw0', 'dws', 'w0', 'wrs', 'wss', 'lTI', 'lTH', 'lTW', 'HH', 'HW', 'CK', 'LD',
             'tiles_a', 'tiles_b', 'n_mtiles', 'n_ntiles', 'blk_begin', 'accumulate', 'dma')] + [
         ('x_bytes', C.c_uint), ('w_bytes', C.c_uint), ('magic_spp', C.c_uint), ('mt_r', C.c_int), ('lwn', C.c_int), ('nt', C.c_int),
-        ('magic_hw', C.c_uint), ('magic_hh', C.c_uint), ('tpb', C.c_int), ('wres', C.c_int)]
+        ('magic_hw', C.c_uint), ('magic_hh', C.c_uint), ('tpb', C.c_int), ('wres', C.c_int), ('bnf', c_fp)]
+
+
+class BnFinalizeArgs(C.Structure):
+    _fields_ = [('gamma', c_fp), ('beta', c_fp), ('scale', c_fp), ('shift', c_fp), ('mean', c_fp), ('invstd', c_fp),
+                ('running_mean', c_fp), ('running_var', c_fp), ('counter', c_fp), ('count', C.c_double), ('eps', C.c_float),
+                ('momentum', C.c_float)]
 
 
 class WgradProb(C.Structure):
@@ -49,6 +55,7 @@ class TermBwdArgs(C.Structure):
                 ('c1', c_fp), ('c2', c_fp), ('dsrc', c_fp), ('partials', c_fp),
                 ('N', C.c_int), ('Hs', C.c_int), ('Ws', C.c_int), ('C', C.c_int), ('up', C.c_int),
                 ('relu', C.c_int), ('accumulate', C.c_int), ('magic_w', C.c_uint), ('magic_h', C.c_uint),
+                ('dgamma', c_fp), ('dbeta', c_fp), ('counter', c_fp), ('count', C.c_double), ('acc_param', C.c_int),
                 ('dsrc2', c_fp), ('accumulate2', C.c_int)]
 
 

@@ -35,6 +35,23 @@ extern "C" {
  * covers forward convolutions (any R, S, stride, pad), stride-1 data gradients and the parity classes of strided
  * data gradients.  W is pre-packed [tap][Cin/4][Cout][4] by bpb_pack_weights.
  * ------------------------------------------------------------------------------------------------------------------ */
+/* BatchNorm statistics finalisation fused into the producing launch (device-resident record).  The LAST workgroup of the
+   launch to finish (agent-scope ticket on `counter`, which it resets to 0) reduces the per-tile partials in a fixed order
+   and writes what bpb_bn_finalize would have written -- one dependent launch less per BatchNorm on the layer chain. */
+typedef struct BpbBnFinalizeArgs {
+    const float* gamma;
+    const float* beta;
+    float* scale;
+    float* shift;
+    float* mean;
+    float* invstd;
+    float* running_mean;
+    float* running_var;
+    int* counter;
+    double count;
+    float eps, momentum;
+} BpbBnFinalizeArgs;
+
 typedef struct BpbConvProb {
     const float* x;
     const float* w;
@@ -64,6 +81,7 @@ typedef struct BpbConvProb {
     unsigned magic_hw, magic_hh;   // ceil(2^32/d) for d = HW, HH (staging index split without idiv)
     int tpb;                // consecutive M tiles walked by one workgroup (>= 1); grid = ceil(n_mtiles / tpb) * n_ntiles
     int wres;               // 1: the weight tiles of all Cin/CK chunks stay resident in LDS for the whole workgroup
+    const BpbBnFinalizeArgs* bnf;   // optional (device pointer, needs `stats`): fused BatchNorm finalisation
 } BpbConvProb;
 
 /* weight-gradient problem: dW[t][ci][co] = sum_{n,a,b} x[n, a*sa + t/S + ih0, b*sa + t%S + iw0, ci] * dy[n,a,b,co] */
@@ -122,6 +140,11 @@ typedef struct BpbTermBwdArgs {
     int N, Hs, Ws, C, up;   // src spatial dims; out dims are Hs<<up, Ws<<up
     int relu, accumulate;
     unsigned magic_w, magic_h;   // for Ws, Hs
+    float* dgamma;          // BN reduce with fused finalisation (counter != nullptr): parameter gradients (+= if acc_param),
+    float* dbeta;           //   c1 / c2 are written by the last workgroup of the reduce launch
+    int* counter;
+    double count;
+    int acc_param;
     float* dsrc2;           // BN apply only, optional: an identity term of the same fuse op at the same resolution
     int accumulate2;        //   (the residual skip): dsrc2 (+)= G is written by the same pass (one launch, dout/out read once)
 } BpbTermBwdArgs;

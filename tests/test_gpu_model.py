@@ -246,3 +246,46 @@ def test_fused_adam_state_interchanges_with_torch_adam(tmp_path):
         assert torch.equal(a, b), n
     for (n, a), b in zip(m1.named_parameters(), m4.parameters()):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), n
+
+
+def test_repeated_steps_are_bit_identical_and_fused_finalize_matches_separate_launches():
+    """The BatchNorm statistics are finalised by the last workgroup of the producing launch (agent-scope ticket).  The same
+    batch must give bit-identical outputs and gradients on every repetition (ticket counters reset, no stale partials), and
+    the same results as the plan with separate finalize launches up to fp64 summation order."""
+    import bpbreid_amd.graph as G
+    cfg = Cm.make_cfg('hrnet_w8', 3, 32)
+    imgs, masks, pids = Cm.synth_batch(8, 128, 64, 3, 8)
+    imgs, masks, pids = imgs.to(DEV), masks.to(DEV), pids.to(DEV)
+
+    def run(fused, reps):
+        old = os.environ.get('BPB_FUSE_FINALIZE')
+        os.environ['BPB_FUSE_FINALIZE'] = '1' if fused else '0'
+        try:
+            model = Cm.fill_state_dict_(bpbreid(8, config=cfg, pretrained=False)).to(DEV)
+            eng = ImagePartBasedEngine(model, optimizer=FusedAdam(model), losses_weights=WEIGHTS_DEFAULT)
+            model.train()
+            res = []
+            for _ in range(reps):
+                out = model(imgs, external_parts_masks=masks)
+                loss, _ = eng.combine_losses(out[1], out[0], out[2], pids, out[3], masks, bpa_weight=0.35)
+                loss.backward()
+                torch.cuda.synchronize()
+                res.append((out[0]['bn_foreg'].clone(), out[4].clone(), model.arena()['grad'].clone(), float(loss)))
+            plan = next(iter(model._plans.values()))
+            return res, plan.net.fuse_finalize
+        finally:
+            if old is None:
+                os.environ.pop('BPB_FUSE_FINALIZE', None)
+            else:
+                os.environ['BPB_FUSE_FINALIZE'] = old
+
+    fused, flag = run(True, 4)
+    assert flag is True
+    for r in fused[1:]:
+        assert torch.equal(r[0], fused[0][0]) and torch.equal(r[1], fused[0][1]) and torch.equal(r[2], fused[0][2])
+    sep, flag = run(False, 1)
+    assert flag is False
+    assert abs(sep[0][3] - fused[0][3]) < 1e-5 * abs(sep[0][3])
+    assert (sep[0][1] - fused[0][1]).abs().max() < 1e-4 * fused[0][1].abs().max()
+    gs, gf = sep[0][2], fused[0][2]
+    assert torch.nn.functional.cosine_similarity(gs, gf, dim=0) > 0.99999
