@@ -136,6 +136,8 @@ def roofline(model, plan):
     agg = {}
     for meta, ms in rows:
         lab = meta['label']
+        if lab in ('dep', 'fork', 'join'):            # stream-ordering records, not kernels
+            continue
         sym = lab.split(' ', 1)[1] if ' ' in lab else lab
         a = agg.setdefault(sym, {'ms': 0.0, 'flops': 0.0, 'bytes': 0.0, 'launches': 0})
         a['ms'] += ms

@@ -4,6 +4,7 @@
 // per-launch argument marshalling.  This is the native counterpart of the reference's module-by-module
 // Python dispatch (torchreid/models/hrnet.py:532-576 runs ~650 nn.Module calls per forward).
 // The same array can be recorded into a hipGraph by capturing the stream around bpb_plan_run.
+#include <cstdlib>
 #include <vector>
 
 #include "bpb_common.h"
@@ -46,10 +47,28 @@ static hipEvent_t next_event()
     return e;
 }
 
+// BPB_SINGLE_STREAM=1 (measurement aid): every record goes to the caller's stream, so that a kernel trace shows each kernel
+// alone on the GPU (the per-kernel averages then match bench.py's live per-launch timings).
+static bool single_stream()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("BPB_SINGLE_STREAM");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v == 1;
+}
+
 extern "C" int bpb_plan_run(const BpbPlanOp* ops, int nops, hipStream_t stream)
 {
+    const bool serial = single_stream();
     for (int k = 0; k < nops; ++k) {
         const BpbPlanOp& o = ops[k];
+        if (serial) {
+            if (o.kind != BPB_OP_FORK && o.kind != BPB_OP_JOIN && o.kind != BPB_OP_DEP)
+                if (const int rc = run_one(o, k, stream)) return rc;
+            continue;
+        }
         if (o.kind == BPB_OP_FORK || o.kind == BPB_OP_JOIN) {   // i0 = bit mask of side slots (bit s-1 = slot s)
             if (int rc = ensure_streams()) return rc;
             if (o.kind == BPB_OP_FORK) {

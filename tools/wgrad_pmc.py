@@ -1,0 +1,37 @@
+"""GPU probe: the weight-gradient launch of one conv shape, repeated; run under rocprofv3 --pmc for its SQ counters."""
+import os, sys, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT]
+import torch
+from bpbreid_amd import native as nv
+from bpbreid_amd.graph import Net, Act
+
+dev = torch.device('cuda', 0)
+nv.init_device()
+h, w, cin, cout, k = [int(a) for a in sys.argv[1:6]]
+reps = int(sys.argv[6]) if len(sys.argv) > 6 else 10
+net = Net(dev)
+net.wgrad_streams = False
+x = Act(net, 64, h, w, cin)
+x.buf.normal_()
+wt = torch.randn(cout, cin, k, k, device=dev) * 0.05
+wt.grad = torch.zeros_like(wt)
+g_, b_ = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+g_.grad, b_.grad = torch.zeros_like(g_), torch.zeros_like(b_)
+node = net.conv(x, wt, 1, k // 2, bn=(g_, b_, torch.zeros(cout, device=dev), torch.ones(cout, device=dev)))
+out = net.fuse([(node, 0)], relu=True)
+net.finalize(True)
+net.run(net.plan_train)
+out.grad.normal_()
+net.run(net.plan_bwd)
+ops = [i for i, m in enumerate(net.plan_bwd[2]) if m['label'].startswith('conv_wgrad')]
+one = (nv.PlanOp * 1)(net.plan_bwd[0][ops[0]])
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+torch.cuda.synchronize()
+s.record()
+for _ in range(reps):
+    nv.call('bpb_plan_run', C.cast(one, C.c_void_p), 1, nv.stream())
+e.record()
+torch.cuda.synchronize()
+wp = net.debug_wgrads[0][0]
+print('wgrad %dx%d %d->%d k%d: %.1f us, nsplit=%d mtiles=%d dma=%d' % (h, w, cin, cout, k, s.elapsed_time(e) * 1e3 / reps, wp.nsplit, wp.n_mtiles, wp.dma))
