@@ -302,6 +302,14 @@ int bpb_eval_rank(const float* distmat, const int64_t* q_pids, const int64_t* g_
                   const int64_t* g_camids, int Q, int G, int max_rank, int nthreads, float* cmc_out, double* map_out,
                   int* num_valid_out, int32_t* indices_out);
 
+/* ---- input side: torchreid/data/masks_transforms/mask_transform.py:20-85 chained as in torchreid/data/transforms.py:133-158
+   (grouping -> background channel -> soft-max x weight | normalise -> nearest resize), raw [N][Cin][H][W] -> out [N][K+1][Ho][Wo].
+   group_offsets [K+1] / group_channels [...]: CSR list of source channels per part (both NULL: K == Cin, no grouping).
+   bg_strategy: 0 'sum', 1 'threshold', 2 'diff_from_max'.  softmax_weight <= 0 -> masks / masks.sum(dim=0). */
+int bpb_mask_preprocess(const float* raw, const int* group_offsets, const int* group_channels, int N, int Cin, int H, int W, int K,
+                        int Ho, int Wo, int combine_sum, int bg_strategy, float softmax_weight, float threshold, float* out,
+                        hipStream_t stream);
+
 /* ---- launch-plan executor: the static op list of one forward / backward (hrnet.py:532-576, resnet.py:342-358) ------ */
 int bpb_plan_run(const BpbPlanOp* ops, int nops, hipStream_t stream);
 /* measurement only: per-op elapsed milliseconds via HIP events on `stream` (synchronises) */

@@ -505,3 +505,35 @@ def test_fused_adam_matches_torch():
     for p, r in zip(m.parameters(), ref):
         assert rel_err(p.data, r.data) < 1e-6
     assert int(opt.step_dev) == 3 == opt.step_index
+
+
+def test_mask_preprocessing_kernel_against_reference_golden(golden_dir):
+    """bpb_mask_preprocess vs the real reference's transform chain (tests/golden/masks_pre.npz), then at full batch size
+    (64 x 36 x 256 x 128 -> 64 x 6 x 64 x 32) against the oracle and through the soft-max's sum-to-one property."""
+    from bpbreid_amd.data import MaskPreprocessor
+    from oracle import data as OD
+    z = np.load(os.path.join(golden_dir, 'masks_pre.npz'))
+    raw = torch.from_numpy(z['raw'])
+    for key in z['cases']:
+        name, strat, sw, thr, scale = str(key).split('|')
+        mp = MaskPreprocessor(raw.shape[2], raw.shape[3], int(scale), background_computation_strategy=strat,
+                              softmax_weight=float(sw), mask_filtering_threshold=float(thr))
+        if 'goff/' + key in z.files:
+            off, ch = z['goff/' + key], z['gch/' + key]
+            mp.groups = [list(map(int, ch[off[i]:off[i + 1]])) for i in range(len(off) - 1)]
+            mp.combine_sum = int(z['sum/' + key])
+        got = mp(raw.to(DEV)).cpu().numpy()
+        ref = z['out/' + key]
+        assert got.shape == ref.shape, key
+        assert np.allclose(got, ref, atol=2e-6, equal_nan=True), (key, np.nanmax(np.abs(got - ref)))
+    g = torch.Generator().manual_seed(3)
+    big = torch.rand(64, 36, 256, 128, generator=g) ** 3
+    off, ch = z['goff/five_v|threshold|15|0.5|4'], z['gch/five_v|threshold|15|0.5|4']
+    groups = [list(map(int, ch[off[i]:off[i + 1]])) for i in range(len(off) - 1)]
+    mp = MaskPreprocessor(256, 128, 4)
+    mp.groups = groups
+    out = mp(big.to(DEV))
+    assert out.shape == (64, 6, 64, 32)
+    assert (out.sum(1) - 1).abs().max() < 1e-5 and bool((out >= 0).all())
+    ref = OD.preprocess_masks(big[:4], 256, 128, 4, groups)
+    assert (out[:4].cpu() - ref).abs().max() < 2e-6

@@ -289,3 +289,43 @@ def test_repeated_steps_are_bit_identical_and_fused_finalize_matches_separate_la
     assert (sep[0][1] - fused[0][1]).abs().max() < 1e-4 * fused[0][1].abs().max()
     gs, gf = sep[0][2], fused[0][2]
     assert torch.nn.functional.cosine_similarity(gs, gf, dim=0) > 0.99999
+
+
+def test_full_size_properties_config3():
+    """BASELINE config 3 at full size (HRNet-W32, K=5, 64 x 3 x 256 x 128), where the CPU oracle takes minutes: checked through
+    size-independent properties instead.  (a) eval mode: a sample's outputs do not depend on its batch (running statistics)
+    -> rows of the 64-batch equal the same images run as four 16-batches; (b) train mode: permuting the batch permutes the
+    embeddings (batch statistics are permutation invariant up to summation order) and leaves the loss unchanged;
+    (c) boolean visibility scores are consistent with the returned part masks."""
+    k, d, n, h, w, ncls = 5, 512, 64, 256, 128, 751
+    model = Cm.fill_state_dict_(bpbreid(ncls, config=Cm.make_cfg('hrnet32', k, d), pretrained=False)).to(DEV)
+    eng = ImagePartBasedEngine(model, optimizer=FusedAdam(model), losses_weights=WEIGHTS_MARKET, mask_filtering_training=True)
+    imgs, masks, pids = Cm.synth_batch(n, h, w, k, ncls)
+    imgs, masks, pids = imgs.to(DEV), masks.to(DEV), pids.to(DEV)
+    model.train()
+    out = model(imgs, external_parts_masks=masks)          # one train forward first: sane running statistics for (a)
+    loss, _ = eng.combine_losses(out[1], out[0], out[2], pids, out[3], masks, bpa_weight=0.35)
+    emb = {kk: v.clone() for kk, v in out[0].items()}
+    vis_parts, mask_parts = out[1]['parts'].clone(), out[5]['parts'].clone()
+    # (c) part k is visible iff it is the arg-max of the (K+1)-way soft-max at some pixel:
+    #     visible  =>  its probability reaches 1/(K+1) somewhere;   probability > 1/2 somewhere  =>  visible
+    assert vis_parts.dtype is torch.bool and vis_parts.shape == (n, k)
+    amax = mask_parts.flatten(2).amax(-1)
+    assert bool((amax[vis_parts] >= 1.0 / (k + 1) - 1e-6).all()) and bool(vis_parts[amax > 0.5].all())
+    # (b)
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(5)).to(DEV)
+    out_p = model(imgs[perm], external_parts_masks=masks[perm])
+    loss_p, _ = eng.combine_losses(out_p[1], out_p[0], out_p[2], pids[perm], out_p[3], masks[perm], bpa_weight=0.35)
+    for kk in ('bn_foreg', 'parts', 'globl'):
+        a, b = emb[kk][perm], out_p[0][kk]
+        assert (a - b).abs().max() <= 2e-4 * a.abs().max(), kk
+    assert abs(float(loss) - float(loss_p)) <= 1e-4 * abs(float(loss))
+    # (a)
+    model.eval()
+    with torch.no_grad():
+        big = model(imgs, external_parts_masks=masks)
+        big_e, big_v = big[0]['bn_foreg'].clone(), big[1]['parts'].clone()
+        for j in range(0, n, 16):
+            sub = model(imgs[j:j + 16], external_parts_masks=masks[j:j + 16])
+            assert (sub[0]['bn_foreg'] - big_e[j:j + 16]).abs().max() <= 1e-5 * big_e.abs().max()
+            assert torch.equal(sub[1]['parts'], big_v[j:j + 16])
