@@ -867,7 +867,8 @@ int bpb_conv_wgrad(const BpbWgradProb* d_probs, const BpbWgradProb* h_probs, int
         BPB_REQUIRE(p.LD % 4 == 0 && p.LD >= (p.Cin < 32 ? p.Cin : 32), "bpb_conv_wgrad: bad LDS pitch");
         BPB_REQUIRE(p.T >= 1 && p.S >= 1 && p.T % p.S == 0, "bpb_conv_wgrad: T=%d S=%d", p.T, p.S);
         BPB_REQUIRE(p.blk_begin == nblk, "bpb_conv_wgrad: blk_begin mismatch");
-        const int this_ntw = (p.T == 1 && p.Cout >= 128) ? 4 : (p.T == 1 && p.Cout >= 64) ? 2 : 1;
+        const int this_ntw = p.ntw;
+        BPB_REQUIRE(this_ntw == 1 || (p.T == 1 && (this_ntw == 2 || this_ntw == 4)), "bpb_conv_wgrad: ntw=%d (T=%d)", this_ntw, p.T);
         BPB_REQUIRE(ntw == 0 || ntw == this_ntw, "bpb_conv_wgrad: mixed tile widths in one group");
         BPB_REQUIRE(i == 0 || (p.T == 1) == (h_probs[0].T == 1), "bpb_conv_wgrad: 1x1 and spatial filters cannot share a group");
         ntw = this_ntw;

@@ -662,7 +662,11 @@ class Net:
         wp.LD = 36 if x.C >= 32 else x.C + 4
         wp.tiles_a, wp.tiles_b = -(-y.H // th), -(-y.W // tw)
         wp.n_mtiles = (-(-x.N // ti)) * wp.tiles_a * wp.tiles_b
-        ntw = 4 if (t == 1 and cout >= 128) else 2 if (t == 1 and cout >= 64) else 1
+        # 1x1: two 32-channel sub-tiles per workgroup.  Four (a 64 KB dy tile, 86 KB of LDS -> one workgroup per CU, no
+        # double buffer) measured 2.4x slower: 19 vs 45 TFLOP/s on the same FLOPs (64->256 vs 256->64 @64x32).
+        ntw_max = int(os.environ.get('BPB_WGRAD_NTW_MAX', '2'))
+        ntw = min(ntw_max, 4 if cout >= 128 else 2 if cout >= 64 else 1) if t == 1 else 1
+        wp.ntw = ntw
         wp.n_citiles = -(-x.C // 32)
         wp.n_cotiles = -(-cout // (32 * ntw))
         wp.n_tapgroups = 1 if t == 1 else -(-t // 9)
@@ -677,7 +681,8 @@ class Net:
         assert lds1 <= 160 * 1024, 'wgrad tile exceeds LDS'
         # measured on MI355X: the DMA double buffer pays for 1x1 filters (small tiles, 2 workgroups/CU still fit) and loses
         # for 3x3 ones, where two halo images leave one workgroup per CU (65 us vs 53 us on 32->32 @ 64x32, N=64)
-        wp.dma = 1 if (getattr(self, 'use_dma', True) and (t == 1 or os.environ.get('BPB_WGRAD_DMA3') == '1')
+        wp.dma = 1 if (getattr(self, 'use_dma', True) and ((t == 1 and os.environ.get('BPB_WGRAD_DMA1', '1') != '0') or
+                                                          (t > 1 and os.environ.get('BPB_WGRAD_DMA3') == '1'))
                        and 2 * lds1 <= 160 * 1024) else 0
         wp.x_bytes, wp.dy_bytes = x.buf.numel() * 4, gy.numel() * 4
         wp.magic_spp = magic(wp.LD // 4)

@@ -36,7 +36,8 @@ class WgradProb(C.Structure):
         (n, C.c_int) for n in (
             'N', 'Hi', 'Wi', 'Cin', 'A', 'B', 'Cout', 'sa', 'ih0', 'iw0', 'T', 'S', 'lTI', 'lTH', 'lTW', 'HH', 'HW',
             'LD', 'tiles_a', 'tiles_b', 'n_mtiles', 'n_citiles', 'n_cotiles', 'n_tapgroups', 'nsplit', 'blk_begin', 'dma')] + [
-        ('x_bytes', C.c_uint), ('dy_bytes', C.c_uint), ('magic_spp', C.c_uint), ('magic_hw', C.c_uint), ('magic_hh', C.c_uint)]
+        ('x_bytes', C.c_uint), ('dy_bytes', C.c_uint), ('magic_spp', C.c_uint), ('magic_hw', C.c_uint), ('magic_hh', C.c_uint),
+        ('ntw', C.c_int)]
 
 
 class PackProb(C.Structure):

@@ -101,6 +101,7 @@ typedef struct BpbWgradProb {
     int dma;               // 1: double-buffered buffer_load..lds pipeline over the pixel tiles
     unsigned x_bytes, dy_bytes, magic_spp;
     unsigned magic_hw, magic_hh;
+    int ntw;               // 32-channel output sub-tiles per workgroup (1 for spatial filters; 1, 2 or 4 for 1x1)
 } BpbWgradProb;
 
 /* one convolution's weights for bpb_pack_weights: w is OIHW (the state-dict layout) */
