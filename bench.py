@@ -44,6 +44,9 @@ def parse():
     ap.add_argument('--graph', type=int, default=0,
                     help='1: replay the step from one hipGraph (exact, but measured 5 %% slower than eager multi-stream launches: '
                          'the ROCm graph executor serialises more of the branch / weight-gradient streams)')
+    ap.add_argument('--dist-backend', default='nccl', help="'nccl' (= RCCL over xGMI; the default) or 'gloo' (functional check of the "
+                    "multi-process path when the ranks have to share one GPU)")
+    ap.add_argument('--same-data', action='store_true', help=argparse.SUPPRESS)     # tests: every rank gets rank 0's batch
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -175,11 +178,16 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    if args.dist_backend != 'nccl':
+        local = local % torch.cuda.device_count()       # gloo check: ranks may share a device
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
     import common as Cm
     from bpbreid_amd.model import bpbreid
     from bpbreid_amd.engine import ImagePartBasedEngine
@@ -192,7 +200,7 @@ def main():
         broadcast_parameters([arena['param'], arena['fbuf']])
     eng = ImagePartBasedEngine(model, optimizer=FusedAdam(model, lr=3.5e-4, weight_decay=5e-4), losses_weights=WEIGHTS,
                                mask_filtering_training=True, distributed=world > 1)
-    imgs, masks, pids = Cm.synth_batch(args.batch, args.height, args.width, args.parts, args.classes, seed=1234 + rank)
+    imgs, masks, pids = Cm.synth_batch(args.batch, args.height, args.width, args.parts, args.classes, seed=1234 + (0 if args.same_data else rank))
     data = {'image': imgs.to(dev), 'mask': masks.to(dev), 'pid': pids.to(dev)}      # resident in HBM before timing
     step = lambda: eng.forward_backward(data)
     mode = 'eager'

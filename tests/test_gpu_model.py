@@ -329,3 +329,37 @@ def test_full_size_properties_config3():
             sub = model(imgs[j:j + 16], external_parts_masks=masks[j:j + 16])
             assert (sub[0]['bn_foreg'] - big_e[j:j + 16]).abs().max() <= 1e-5 * big_e.abs().max()
             assert torch.equal(sub[1]['parts'], big_v[j:j + 16])
+
+
+def test_two_rank_data_parallel_matches_single_process(tmp_path):
+    """The N > 1 path end to end (torch.distributed.run, broadcast of the arenas, bucketed gradient all-reduce, 1/world folded
+    into Adam) with two ranks sharing this one GPU over the gloo backend: fed the SAME batch, two data-parallel ranks must
+    reproduce the single-process trajectory (mean of identical gradients = the gradient)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ['--steps', '3', '--warmup', '0', '--backbone', 'hrnet_w8', '--batch', '16', '--height', '128', '--width', '64',
+              '--classes', '32', '--no-cpu-baseline', '--no-roofline', '--same-data']
+    env = dict(os.environ)
+    for kk in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(kk, None)
+    one = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1'] + common, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=300, env=env)
+    assert one.returncode == 0, one.stderr.decode()[-2000:]
+    r1 = json.loads([l for l in one.stdout.decode().splitlines() if l.startswith('{')][-1])
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    two = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                          '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2',
+                          '--dist-backend', 'gloo'] + common, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
+    err = two.stderr.decode()
+    if two.returncode != 0 and ('gloo' in err.lower() and ('cuda' in err.lower() or 'hip' in err.lower()) and 'support' in err.lower()):
+        pytest.skip('this torch build has no gloo support for device tensors')
+    assert two.returncode == 0, err[-3000:]
+    r2 = json.loads([l for l in two.stdout.decode().splitlines() if l.startswith('{')][-1])
+    assert r2['n_gpus'] == 2 and r2['config']['global_batch'] == 32 and r2['scaling'] == 'weak'
+    assert abs(r2['config']['final_loss'] - r1['config']['final_loss']) <= 2e-4 * abs(r1['config']['final_loss']), (r1, r2)
