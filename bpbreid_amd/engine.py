@@ -16,7 +16,7 @@ import torch.nn.functional as F
 from . import native as nv
 from .distributed import GradAllReducer
 from .losses import GiLtLoss, BodyPartAttentionLoss
-from .metrics import compute_distance_matrix_using_bp_features, evaluate_rank
+from .metrics import compute_distance_matrix_using_bp_features, evaluate_rank, re_ranking
 from .model import bn_correspondants, PIXELS
 from .optim import FusedAdam
 
@@ -169,10 +169,14 @@ class ImagePartBasedEngine:
 
     @torch.no_grad()
     def evaluate(self, qf, gf, q_vis, g_vis, q_pids, g_pids, q_camids, g_camids, dist_metric='euclidean',
-                 normalize_feature=True, max_rank=50):
+                 normalize_feature=True, max_rank=50, rerank=False):
         if normalize_feature:
             qf, gf = F.normalize(qf, p=2, dim=-1), F.normalize(gf, p=2, dim=-1)       # engine.py:558
-        distmat, body_parts_distmat = compute_distance_matrix_using_bp_features(
-            qf, gf, q_vis, g_vis, self.dist_combine_strat, self.batch_size_pairwise_dist_matrix, True, dist_metric)
-        res = evaluate_rank(distmat.numpy(), q_pids, g_pids, q_camids, g_camids, max_rank=max_rank)
-        return res['cmc'], res['mAP'], distmat, body_parts_distmat
+        bp = lambda a, b, va, vb: compute_distance_matrix_using_bp_features(
+            a, b, va, vb, self.dist_combine_strat, self.batch_size_pairwise_dist_matrix, True, dist_metric)
+        distmat, body_parts_distmat = bp(qf, gf, q_vis, g_vis)
+        ranked = distmat.numpy()
+        if rerank:                                                   # part_based_engine.py:218-226
+            ranked = re_ranking(ranked, bp(qf, qf, q_vis, q_vis)[0].numpy(), bp(gf, gf, g_vis, g_vis)[0].numpy())
+        res = evaluate_rank(ranked, q_pids, g_pids, q_camids, g_camids, max_rank=max_rank)
+        return res['cmc'], res['mAP'], (torch.from_numpy(ranked) if rerank else distmat), body_parts_distmat

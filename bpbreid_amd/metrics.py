@@ -101,3 +101,19 @@ def evaluate_rank(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50, eval
     if return_indices:
         res['indices'] = idx
     return res
+
+
+def re_ranking(q_g_dist, q_q_dist, g_g_dist, k1=20, k2=6, lambda_value=0.3, nthreads=None):
+    """k-reciprocal re-ranking with the reference's signature (torchreid/utils/rerank.py:30; engine.py:433-437): numpy
+    distance matrices in, re-ranked [num_query, num_gallery] float32 matrix out.  Native, threaded (csrc/rerank.cpp)."""
+    qg = np.ascontiguousarray(np.asarray(q_g_dist, dtype=np.float32))
+    qq = np.ascontiguousarray(np.asarray(q_q_dist, dtype=np.float32))
+    gg = np.ascontiguousarray(np.asarray(g_g_dist, dtype=np.float32))
+    nq, ng = qg.shape
+    if qq.shape != (nq, nq) or gg.shape != (ng, ng):
+        raise ValueError('re_ranking: expected q_q %s and g_g %s, got %s and %s' % ((nq, nq), (ng, ng), qq.shape, gg.shape))
+    out = np.empty((nq, ng), dtype=np.float32)
+    pt = lambda a: a.ctypes.data_as(C.c_void_p)
+    nthreads = nthreads or min(64, os.cpu_count() or 1)
+    nv.check(nv.lib().bpb_re_ranking(pt(qg), pt(qq), pt(gg), nq, ng, int(k1), int(k2), float(lambda_value), int(nthreads), pt(out)))
+    return out

@@ -158,7 +158,7 @@ PROTOS = {
     'bpb_scale': 'ppfplip', 'bpb_adam_step': 'ppppppifffffifpp', 'bpb_fill': 'pflp', 'bpb_plan_run': 'pip', 'bpb_plan_run_timed': 'pipp',
     'bpb_part_distance': 'ppppiiiiiiipppppip', 'bpb_part_distance_fill': 'plpp',
     'bpb_mask_preprocess': 'pppiiiiiiiiiffpp',
-    'bpb_eval_rank': 'pppppiiiipppp',
+    'bpb_eval_rank': 'pppppiiiipppp', 'bpb_re_ranking': 'pppiiiifip',
 }
 
 EXPORTS = [
@@ -170,5 +170,5 @@ EXPORTS = [
     'bpb_head_bwd_params', 'bpb_head_bwd_dx', 'bpb_gemm', 'bpb_colsum', 'bpb_bn1d_fwd', 'bpb_bn1d_bwd',
     'bpb_ce_label_smooth', 'bpb_pixel_ce', 'bpb_part_triplet', 'bpb_part_triplet_bwd', 'bpb_scale', 'bpb_adam_step',
     'bpb_fill', 'bpb_plan_run', 'bpb_plan_run_timed', 'bpb_part_distance', 'bpb_part_distance_fill', 'bpb_eval_rank',
-    'bpb_mask_preprocess',
+    'bpb_mask_preprocess', 'bpb_re_ranking',
 ]

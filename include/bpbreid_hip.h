@@ -303,6 +303,11 @@ int bpb_eval_rank(const float* distmat, const int64_t* q_pids, const int64_t* g_
                   const int64_t* g_camids, int Q, int G, int max_rank, int nthreads, float* cmc_out, double* map_out,
                   int* num_valid_out, int32_t* indices_out);
 
+/* k-reciprocal re-ranking, torchreid/utils/rerank.py:30-117 (host, threaded): distance matrices are host fp32 row-major;
+   final_dist [Q][G].  k1 + 1 <= Q + G. */
+int bpb_re_ranking(const float* q_g_dist, const float* q_q_dist, const float* g_g_dist, int Q, int G, int k1, int k2,
+                   float lambda_value, int nthreads, float* final_dist);
+
 /* ---- input side: torchreid/data/masks_transforms/mask_transform.py:20-85 chained as in torchreid/data/transforms.py:133-158
    (grouping -> background channel -> soft-max x weight | normalise -> nearest resize), raw [N][Cin][H][W] -> out [N][K+1][Ho][Wo].
    group_offsets [K+1] / group_channels [...]: CSR list of source channels per part (both NULL: K == Cin, no grouping).

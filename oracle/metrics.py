@@ -96,3 +96,42 @@ def evaluate_rank(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50, eval
     if eval_metric != 'default':
         raise ValueError(eval_metric)
     return eval_market1501(distmat, q_pids, g_pids, q_camids, g_camids, max_rank)
+
+
+def re_ranking(q_g_dist, q_q_dist, g_g_dist, k1=20, k2=6, lambda_value=0.3):
+    """torchreid/utils/rerank.py:30-117 restated (dense V, python loops: small cases only)."""
+    nq, ng = q_g_dist.shape
+    n = nq + ng
+    full = np.block([[q_q_dist, q_g_dist], [q_g_dist.T, g_g_dist]]).astype(np.float32)
+    d2 = np.power(full, 2).astype(np.float32)
+    od = np.transpose(1. * d2 / np.max(d2, axis=0))
+    rank = np.argsort(od, axis=1, kind='stable').astype(np.int32)
+    kh = int(np.around(k1 / 2.)) + 1
+
+    def recip(i, k):
+        fw = rank[i, :k]
+        return fw[[i in rank[f, :k] for f in fw]]
+
+    V = np.zeros_like(od, dtype=np.float32)
+    for i in range(n):
+        base = recip(i, k1 + 1)
+        exp_idx = base
+        for c in base:
+            cr = recip(int(c), kh)
+            if len(np.intersect1d(cr, base)) > 2. / 3 * len(cr):
+                exp_idx = np.append(exp_idx, cr)
+        exp_idx = np.unique(exp_idx)
+        w = np.exp(-od[i, exp_idx])
+        V[i, exp_idx] = 1. * w / np.sum(w)
+    if k2 != 1:
+        V = np.stack([np.mean(V[rank[i, :k2], :], axis=0) for i in range(n)]).astype(np.float32)
+    jac = np.zeros((nq, n), dtype=np.float32)
+    for i in range(nq):
+        nz = np.where(V[i] != 0)[0]
+        tmin = np.zeros(n, dtype=np.float32)
+        for c in nz:
+            rows = np.where(V[:, c] != 0)[0]
+            tmin[rows] = tmin[rows] + np.minimum(V[i, c], V[rows, c])
+        jac[i] = 1 - tmin / (2. - tmin)
+    final = jac * (1 - lambda_value) + od[:nq] * lambda_value
+    return final[:, nq:]

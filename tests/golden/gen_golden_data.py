@@ -63,3 +63,21 @@ for bs, ni in ((16, 4), (8, 2), (12, 3)):
     seqs['len/%d/%d' % (bs, ni)] = np.int64(len(s))
 np.savez_compressed(os.path.join(HERE, 'sampler.npz'), pids=pids.astype(np.int64), **seqs)
 print('sampler.npz:', {k: (v.shape if hasattr(v, 'shape') else v) for k, v in seqs.items()})
+
+# k-reciprocal re-ranking (utils/rerank.py): small random feature sets, euclidean distances like engine.py:431-437
+from torchreid.utils.rerank import re_ranking                  # noqa: E402
+from torchreid import metrics as RM                            # noqa: E402
+rr = {}
+g = torch.Generator().manual_seed(77)
+for tag, (nq, ng, dim, k1, k2, lam) in {'a': (12, 40, 16, 20, 6, 0.3), 'b': (7, 30, 8, 6, 3, 0.5), 'c': (5, 25, 8, 5, 1, 0.3)}.items():
+    cent = torch.randn(8, dim, generator=g)
+    qf = torch.nn.functional.normalize(cent[torch.randint(0, 8, (nq,), generator=g)] + 0.3 * torch.randn(nq, dim, generator=g), dim=1)
+    gf = torch.nn.functional.normalize(cent[torch.randint(0, 8, (ng,), generator=g)] + 0.3 * torch.randn(ng, dim, generator=g), dim=1)
+    qg = RM.compute_distance_matrix(qf, gf, 'euclidean').numpy()
+    qq = RM.compute_distance_matrix(qf, qf, 'euclidean').numpy()
+    gg = RM.compute_distance_matrix(gf, gf, 'euclidean').numpy()
+    rr['%s/qg' % tag], rr['%s/qq' % tag], rr['%s/gg' % tag] = qg, qq, gg
+    rr['%s/params' % tag] = np.array([k1, k2, lam], dtype=np.float64)
+    rr['%s/out' % tag] = re_ranking(qg, qq, gg, k1=k1, k2=k2, lambda_value=lam)
+np.savez_compressed(os.path.join(HERE, 'rerank.npz'), **rr)
+print('rerank.npz:', {k: v.shape for k, v in rr.items() if k.endswith('/out')})

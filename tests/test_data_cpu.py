@@ -57,3 +57,41 @@ def test_mask_preprocessor_argument_checks():
     from bpbreid_amd import native as nv
     with pytest.raises(nv.NativeError):
         mp(torch.zeros(1, 3, 8, 8))               # no CPU fallback
+
+
+def test_re_ranking_native_and_oracle_match_reference(golden_dir):
+    """k-reciprocal re-ranking (utils/rerank.py): the oracle restatement and the native threaded implementation against the
+    reference's output on three small cases (default k1=20/k2=6, small k, and k2=1 = no query expansion)."""
+    from oracle import metrics as OM
+    from bpbreid_amd.metrics import re_ranking
+    z = np.load(os.path.join(golden_dir, 'rerank.npz'))
+    for tag in ('a', 'b', 'c'):
+        k1, k2, lam = z[tag + '/params']
+        qg, qq, gg, ref = z[tag + '/qg'], z[tag + '/qq'], z[tag + '/gg'], z[tag + '/out']
+        got_o = OM.re_ranking(qg, qq, gg, int(k1), int(k2), float(lam))
+        assert np.allclose(got_o, ref, atol=2e-6), (tag, np.abs(got_o - ref).max())
+        for nth in (1, 4):
+            got = re_ranking(qg, qq, gg, int(k1), int(k2), float(lam), nthreads=nth)
+            assert got.dtype == np.float32 and got.shape == ref.shape
+            assert np.allclose(got, ref, atol=2e-6), (tag, nth, np.abs(got - ref).max())
+            assert np.array_equal(np.argsort(got, axis=1, kind='stable')[:, :5], np.argsort(ref, axis=1, kind='stable')[:, :5])
+    with pytest.raises(ValueError):
+        re_ranking(np.zeros((3, 4)), np.zeros((2, 2)), np.zeros((4, 4)))
+    from bpbreid_amd import native as nv
+    with pytest.raises(nv.NativeError):
+        re_ranking(np.zeros((2, 3), np.float32), np.zeros((2, 2), np.float32), np.zeros((3, 3), np.float32), k1=20)   # k1 + 1 > Q + G
+
+
+def test_re_ranking_medium_size_against_oracle():
+    from oracle import metrics as OM
+    from bpbreid_amd.metrics import re_ranking
+    g = torch.Generator().manual_seed(11)
+    nq, ng, dim = 40, 300, 32
+    cent = torch.randn(25, dim, generator=g)
+    qf = torch.nn.functional.normalize(cent[torch.randint(0, 25, (nq,), generator=g)] + 0.4 * torch.randn(nq, dim, generator=g), dim=1)
+    gf = torch.nn.functional.normalize(cent[torch.randint(0, 25, (ng,), generator=g)] + 0.4 * torch.randn(ng, dim, generator=g), dim=1)
+    d = lambda a, b: torch.cdist(a, b).numpy().astype(np.float32)
+    qg, qq, gg = d(qf, gf), d(qf, qf), d(gf, gf)
+    ref = OM.re_ranking(qg, qq, gg)
+    got = re_ranking(qg, qq, gg)
+    assert np.allclose(got, ref, atol=3e-6), np.abs(got - ref).max()
