@@ -63,6 +63,26 @@ __global__ __launch_bounds__(1024) void bpb_bn_finalize_kernel(const double* __r
     }
 }
 
+// eval mode, every BatchNorm of the network in one launch (descriptor table, 256 channels per block)
+__global__ __launch_bounds__(256) void bpb_bn_eval_affine_batched_kernel(const BpbBnEvalDesc* __restrict__ descs, int n, float eps)
+{
+    int bid = blockIdx.x;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].blk_begin <= bid) lo = mid; else hi = mid - 1;
+    }
+    const BpbBnEvalDesc D = descs[lo];
+    const int c = (bid - D.blk_begin) * 256 + threadIdx.x;
+    if (c < D.C) {
+        const float invstd = 1.f / sqrtf(D.running_var[c] + eps);
+        const float g = D.gamma ? D.gamma[c] : 1.f, b = D.beta ? D.beta[c] : 0.f;
+        const float sc = g * invstd;
+        D.scale[c] = sc;
+        D.shift[c] = b - D.running_mean[c] * sc;
+    }
+}
+
 // eval mode: affine from running statistics
 __global__ void bpb_bn_eval_affine_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                           const float* __restrict__ running_mean, const float* __restrict__ running_var,
@@ -432,6 +452,14 @@ int bpb_bn_finalize(const double* partials, int nparts, int C, double count, con
     BPB_REQUIRE(nparts >= 1 && C >= 1 && count >= 1.0, "bpb_bn_finalize: bad sizes");
     hipLaunchKernelGGL(bpb_bn_finalize_kernel, dim3(bpb_cdiv(C, 32)), dim3(1024), 0, stream, partials, nparts, C, count,
                        gamma, beta, eps, momentum, scale, shift, mean, invstd, running_mean, running_var);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_bn_eval_affine_batched(const BpbBnEvalDesc* d_descs, int ndescs, int total_blocks, float eps, hipStream_t stream)
+{
+    BPB_REQUIRE(ndescs >= 1 && total_blocks >= 1, "bpb_bn_eval_affine_batched: empty");
+    hipLaunchKernelGGL(bpb_bn_eval_affine_batched_kernel, dim3(total_blocks), dim3(256), 0, stream, d_descs, ndescs, eps);
     BPB_LAUNCH_OK();
     return 0;
 }

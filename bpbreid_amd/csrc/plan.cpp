@@ -158,6 +158,9 @@ static int run_one(const BpbPlanOp& o, int k, hipStream_t stream)
                 rc = bpb_bn_eval_affine(o.i[0], (const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2],
                                         (const float*)o.p[3], o.f[0], (float*)o.p[4], (float*)o.p[5], stream);
                 break;
+            case BPB_OP_BN_EVAL_BATCHED:   // p0 device descs, i0 count, i1 total blocks, f0 eps
+                rc = bpb_bn_eval_affine_batched((const BpbBnEvalDesc*)o.p[0], o.i[0], o.i[1], o.f[0], stream);
+                break;
             case BPB_OP_FUSE_FWD:   // p0 host BpbFuseArgs
                 rc = bpb_fuse_fwd((const BpbFuseArgs*)o.p[0], stream);
                 break;

@@ -17,7 +17,7 @@ import os
 import torch
 
 from . import native as nv
-from .native import ConvProb, WgradProb, PackProb, FuseArgs, TermBwdArgs, BilinearArgs, BnFinalizeArgs, PlanOp, magic, ptr
+from .native import BnEvalDesc, ConvProb, WgradProb, PackProb, FuseArgs, TermBwdArgs, BilinearArgs, BnFinalizeArgs, PlanOp, magic, ptr
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -382,6 +382,8 @@ class Net:
             self.fwd_train.add(pack_op, 'pack_weights')
             self.fwd_eval.add(pack_op, 'pack_weights')
         both = (self.fwd_train, self.fwd_eval)
+        eval_bns = []
+        eval_affine_at = len(self.fwd_eval)      # position of the batched eval-affine record (filled in after the walk)
 
         # ---- forward
         for (kind, pay), slot in zip(self.nodes, self.node_slots):
@@ -431,9 +433,7 @@ class Net:
                             nv.OP_BN_FINALIZE, ints=(prob.n_mtiles, y.C), floats=(BN_EPS, BN_MOMENTUM), doubles=(count,),
                             ptrs=(cv.stats_buf, bn.weight, bn.bias, bn.scale, bn.shift, bn.mean, bn.invstd, bn.running_mean,
                                   bn.running_var)), 'bn_finalize')
-                    self.fwd_eval.add(self._op(
-                        nv.OP_BN_EVAL_AFFINE, ints=(y.C,), floats=(BN_EPS,),
-                        ptrs=(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.scale, bn.shift)), 'bn_eval_affine')
+                    eval_bns.append(bn)       # scale / shift from the running statistics: one batched launch up front
             elif kind == 'fuse':
                 out, terms, relu = pay
                 fa = FuseArgs()
@@ -474,6 +474,19 @@ class Net:
                         pl.add(op, 'bilinear_concat_fwd', 0, 4.0 * (a.buf.numel() + a.N * out.H * out.W * a.C))
                     c0 += a.C
         self.fwd_train.slot = self.fwd_eval.slot = 0
+        if eval_bns:
+            descs = (BnEvalDesc * len(eval_bns))()
+            blk = 0
+            for d, bn in zip(descs, eval_bns):
+                d.gamma, d.beta = bn.weight.data_ptr(), bn.bias.data_ptr()
+                d.running_mean, d.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                d.scale, d.shift = bn.scale.data_ptr(), bn.shift.data_ptr()
+                d.C, d.blk_begin = bn.scale.numel(), blk
+                blk += -(-bn.scale.numel() // 256)
+            op = self._op(nv.OP_BN_EVAL_BATCHED, ints=(len(eval_bns), blk), floats=(BN_EPS,), ptrs=(self._dev_struct(descs),))
+            op.i[10] = 0
+            self.fwd_eval.insert(eval_affine_at, op)
+            self.fwd_eval.meta.insert(eval_affine_at, {'label': 'bn_eval_affine_batched', 'flops': 0.0, 'bytes': 0.0})
         if train_backward:
             self._emit_backward()
         self.plan_train = self._freeze(self.fwd_train)

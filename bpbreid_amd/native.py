@@ -31,6 +31,11 @@ class BnFinalizeArgs(C.Structure):
                 ('momentum', C.c_float)]
 
 
+class BnEvalDesc(C.Structure):
+    _fields_ = [('gamma', c_fp), ('beta', c_fp), ('running_mean', c_fp), ('running_var', c_fp), ('scale', c_fp), ('shift', c_fp),
+                ('C', C.c_int), ('blk_begin', C.c_int)]
+
+
 class WgradProb(C.Structure):
     _fields_ = [('x', c_fp), ('dy', c_fp), ('ws', c_fp)] + [
         (n, C.c_int) for n in (
@@ -71,7 +76,7 @@ class PlanOp(C.Structure):
 
 (OP_CONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL_AFFINE, OP_FUSE_FWD, OP_TERM_BWD,
  OP_BN_BWD_FINALIZE, OP_NCHW_TO_NHWC4, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_BILINEAR_FWD, OP_BILINEAR_BWD, OP_FILL,
- OP_CHANNEL_STATS, OP_FORK, OP_JOIN, OP_DEP) = range(19)
+ OP_CHANNEL_STATS, OP_FORK, OP_JOIN, OP_DEP, OP_BN_EVAL_BATCHED) = range(20)
 
 
 def magic(d):
@@ -157,7 +162,7 @@ PROTOS = {
     'bpb_part_triplet': 'pllppipiiiiffpppppp', 'bpb_part_triplet_bwd': 'pllppfiiipllip',
     'bpb_scale': 'ppfplip', 'bpb_adam_step': 'ppppppifffffifpp', 'bpb_fill': 'pflp', 'bpb_plan_run': 'pip', 'bpb_plan_run_timed': 'pipp',
     'bpb_part_distance': 'ppppiiiiiiipppppip', 'bpb_part_distance_fill': 'plpp',
-    'bpb_mask_preprocess': 'pppiiiiiiiiiffpp',
+    'bpb_mask_preprocess': 'pppiiiiiiiiiffpp', 'bpb_bn_eval_affine_batched': 'piifp',
     'bpb_eval_rank': 'pppppiiiipppp', 'bpb_re_ranking': 'pppiiiifip',
 }
 
@@ -170,5 +175,5 @@ EXPORTS = [
     'bpb_head_bwd_params', 'bpb_head_bwd_dx', 'bpb_gemm', 'bpb_colsum', 'bpb_bn1d_fwd', 'bpb_bn1d_bwd',
     'bpb_ce_label_smooth', 'bpb_pixel_ce', 'bpb_part_triplet', 'bpb_part_triplet_bwd', 'bpb_scale', 'bpb_adam_step',
     'bpb_fill', 'bpb_plan_run', 'bpb_plan_run_timed', 'bpb_part_distance', 'bpb_part_distance_fill', 'bpb_eval_rank',
-    'bpb_mask_preprocess', 'bpb_re_ranking',
+    'bpb_mask_preprocess', 'bpb_re_ranking', 'bpb_bn_eval_affine_batched',
 ]

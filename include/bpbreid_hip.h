@@ -113,6 +113,19 @@ typedef struct BpbPackProb {
     int blk_begin;
 } BpbPackProb;
 
+/* one BatchNorm of a batched eval-mode affine launch (bpb_bn_eval_affine_batched): scale = gamma / sqrt(rv + eps),
+   shift = beta - rm * scale for every BatchNorm of the network in ONE launch (blocks of 256 channels, blk_begin prefix) */
+typedef struct BpbBnEvalDesc {
+    const float* gamma;
+    const float* beta;
+    const float* running_mean;
+    const float* running_var;
+    float* scale;
+    float* shift;
+    int C;
+    int blk_begin;
+} BpbBnEvalDesc;
+
 /* out = act(sum_t affine_t(nearest_up_t(src_t))) */
 typedef struct BpbFuseArgs {
     float* out;                         // [N][H][W][C]
@@ -179,7 +192,8 @@ typedef enum BpbOpKind {
     BPB_OP_CHANNEL_STATS = 15,
     BPB_OP_FORK = 16,
     BPB_OP_JOIN = 17,
-    BPB_OP_DEP = 18,   /* i0 = source slot, i1 = destination slot: work recorded later on `destination` waits for everything
+    BPB_OP_DEP = 18,
+    BPB_OP_BN_EVAL_BATCHED = 19,   /* p0 device BpbBnEvalDesc[], i0 count, i1 total blocks, f0 eps */   /* i0 = source slot, i1 = destination slot: work recorded later on `destination` waits for everything
                           recorded so far on `source` (one event record + one stream wait) */
 } BpbOpKind;
 
@@ -215,6 +229,7 @@ int bpb_pack_weights(const BpbPackProb* d_probs, int nprobs, int total_blocks, h
 int bpb_bn_finalize(const double* partials, int nparts, int C, double count, const float* gamma, const float* beta,
                     float eps, float momentum, float* scale, float* shift, float* mean, float* invstd,
                     float* running_mean, float* running_var, hipStream_t stream);
+int bpb_bn_eval_affine_batched(const BpbBnEvalDesc* d_descs, int ndescs, int total_blocks, float eps, hipStream_t stream);
 int bpb_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* scale, float* shift, hipStream_t stream);
 int bpb_channel_stats(const float* x, long P, int C, double* partials, int nblocks, hipStream_t stream);
