@@ -283,7 +283,8 @@ class Net:
         if dma:
             # two workgroups per CU only matter when the launch has more than one workgroup per CU to begin with; a launch
             # of <= 256 workgroups takes the largest chunk that fits (fewer barriers: 65 -> 54 us on 256->256 @8x4)
-            for limit in ((160 * 1024,) if n_blocks <= 256 else (78 * 1024, 160 * 1024)):
+            lim2 = int(os.environ.get('BPB_CONV_LDS2_KB', '78')) * 1024      # budget of a workgroup when two share a CU
+            for limit in ((160 * 1024,) if n_blocks <= 256 else (lim2, 160 * 1024)):
                 fit = [c_ for c_ in cks if lds_bytes(c_, ld_of(c_), 2) <= limit]
                 if fit:
                     choice = (fit[0], 1)
