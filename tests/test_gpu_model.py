@@ -363,3 +363,52 @@ def test_two_rank_data_parallel_matches_single_process(tmp_path):
     r2 = json.loads([l for l in two.stdout.decode().splitlines() if l.startswith('{')][-1])
     assert r2['n_gpus'] == 2 and r2['config']['global_batch'] == 32 and r2['scaling'] == 'weak'
     assert abs(r2['config']['final_loss'] - r1['config']['final_loss']) <= 2e-4 * abs(r1['config']['final_loss']), (r1, r2)
+
+
+@pytest.mark.parametrize('case', [
+    ('hrnet_w8', 2, 3, 96, 64, 7),       # odd batch, non power-of-two map heights (24x16 ... 3x2), K=2 (HRNet itself needs
+                                         # H and W divisible by 32: the reference's nearest x8 up-sampling fails otherwise)
+    ('hrnet_w8', 8, 5, 64, 32, 11),      # K=8, 16x8 maps: the deepest branch is 2x1 pixels
+    ('resnet50', 1, 6, 128, 64, 5),      # K=1
+    ('hrnet_w8', 4, 1, 64, 32, 3),       # a single image: every BatchNorm population is one image
+])
+def test_odd_shapes_forward_loss_and_gradients_against_the_oracle(case):
+    """Shapes outside the fixtures (ragged tiles, tiny maps, K at both ends of its range): embeddings, loss and the gradient
+    direction against the CPU oracle run on the same seeded inputs."""
+    from oracle.bpbreid import BPBreID as OracleModel
+    from oracle import losses as OL
+    backbone, k, n, h, w, ncls = case
+    cfg = Cm.make_cfg(backbone, k, 64)
+    model = Cm.fill_state_dict_(bpbreid(ncls, config=cfg, pretrained=False)).to(DEV)
+    ref = Cm.fill_state_dict_(OracleModel(ncls, cfg)).train()
+    imgs, masks, _ = Cm.synth_batch(n, h, w, k, ncls)
+    pids = (torch.arange(n) // 2) % ncls           # pairs of images per identity: positives and negatives for n >= 3
+    weights = WEIGHTS_DEFAULT if n >= 3 else {kk: dict(v, tr=0.) if 'tr' in v else v for kk, v in WEIGHTS_DEFAULT.items()}
+    eng = ImagePartBasedEngine(model, optimizer=FusedAdam(model), losses_weights=weights)
+    model.train()
+    out = model(imgs.to(DEV), external_parts_masks=masks.to(DEV))
+    loss, _ = eng.combine_losses(out[1], out[0], out[2], pids.to(DEV), out[3], masks.to(DEV), bpa_weight=0.35)
+    loss.backward()
+    torch.cuda.synchronize()
+    rout = ref(imgs, masks)
+    rloss, _ = OL.combined_loss(rout, pids, masks, weights={kk: v for kk, v in weights.items() if kk != 'pixls'})
+    rloss.backward()
+    for kk in ('globl', 'foreg', 'parts', 'bn_foreg'):
+        a, b = out[0][kk].detach().cpu(), rout[0][kk].detach()
+        # (BatchNorm populations of 1..10 elements amplify fp32 round-off here: the tight, fp64-arbitrated bounds are those of
+        #  the golden fixtures; this test is about ragged / degenerate shapes being handled at all)
+        assert (a - b).abs().max() <= 3e-3 * max(1.0, float(b.abs().max())), (case, kk, float((a - b).abs().max()))
+    assert torch.equal(out[1]['parts'].cpu(), rout[1]['parts']), case
+    assert abs(float(loss.detach()) - float(rloss.detach())) <= 2e-3 * abs(float(rloss.detach())), (case, float(loss.detach()), float(rloss.detach()))
+    rp = dict(ref.named_parameters())
+    num = den1 = den2 = 0.0
+    for name, p in model.named_parameters():
+        if p.grad is None or rp[name].grad is None:
+            assert (p.grad is None) == (rp[name].grad is None), name
+            continue
+        r = rp[name].grad.flatten().double()
+        sc = float(r.abs().max().clamp_min(1e-30))
+        g = p.grad.flatten().double().cpu() / sc
+        r = r / sc
+        num += float((g * r).sum()); den1 += float((g * g).sum()); den2 += float((r * r).sum())
+    assert num / (den1 * den2) ** 0.5 > 0.95, (case, num / (den1 * den2) ** 0.5)
