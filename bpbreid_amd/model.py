@@ -257,6 +257,10 @@ class BPBreID(nn.Module):
             raise nv.NativeError('bpbreid_amd.BPBreID.forward needs CUDA/HIP tensors (no CPU fallback)')
         self.arena()
         n, _, h, w = images.shape
+        if self.training and n == 1:
+            # the reference's BatchNorm1d layers (bpbreid.py:335, :405) refuse a single sample in training mode
+            raise ValueError('Expected more than 1 value per channel when training, got input size torch.Size([1, %d])'
+                             % self.dim_reduce_output)
         plan = self._plan(n, h, w, images.device)
         outs = _ModelFn.apply(self._anchor, images, self, plan)
         return plan.pack_outputs(outs)
