@@ -246,7 +246,7 @@ def main():
                    'parallelism': 'dp%d' % world, 'global_batch': args.batch * world, 'final_loss': final_loss,
                    'host_enqueue_ms_per_step': 1e3 * host_enqueue / args.steps, 'launch_mode': mode},
     }
-    if rank == 0 and world == 1 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline:                  # per-GPU figure (the plan of this rank), any world size
         plan = next(iter(model._plans.values()))
         result['roofline'] = roofline(model, plan)
         step_flops = 3.0 * sum(m['flops'] for m in plan.net.plan_train[2])
