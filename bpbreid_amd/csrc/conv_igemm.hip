@@ -283,6 +283,7 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_igemm_kernel(const BpbConvPro
                     const unsigned off = offs[r] + cofs[nt];
                     float v = acc[mt][nt][r] + bias_v[nt];
                     if (accum) v += old[r];
+                    if (P.relu) v = fmaxf(v, 0.f);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, (int)off, 0, 0);
                     const double dv = off < CH_OOB ? (double)v : 0.0;
                     ssum[nt] += dv;
@@ -752,7 +753,8 @@ __global__ void bpb_pack_weights_kernel(const BpbPackProb* __restrict__ probs, i
         r /= P.Cout;
         const int q = (int)(r % (P.Cin_pad >> 2)), t = (int)(r / (P.Cin_pad >> 2));
         const int ci = q * 4 + e;
-        P.wf[i] = ci < P.Cin ? P.w[((size_t)co * P.Cin + ci) * P.T + t] : 0.f;
+        const float sc = P.scale ? P.scale[co] : 1.f;
+        P.wf[i] = ci < P.Cin ? P.w[((size_t)co * P.Cin + ci) * P.T + t] * sc : 0.f;
     }
     if (P.wd) {
         const long nd = (long)P.T * P.Cout * P.Cin_pad;

@@ -122,6 +122,7 @@ class Net:
         self.wgrad_streams = os.environ.get('BPB_WGRAD_STREAMS', '1') != '0'
         self.interleave = os.environ.get('BPB_INTERLEAVE', '1') != '0'
         self.merge_identity = os.environ.get('BPB_MERGE_IDENTITY', '1') != '0'
+        self.fold_eval_bn = os.environ.get('BPB_FOLD_EVAL_BN', '1') != '0'
         # BatchNorm finalisation by the last workgroup of the producing launch: implemented, tested (bit-reproducible), but
         # measured 2-3 % slower than the separate 2-8 workgroup launches (serial tail of the last workgroup) -> opt-in
         self.fuse_finalize = os.environ.get('BPB_FUSE_FINALIZE', '0') == '1'
@@ -364,6 +365,7 @@ class Net:
         dev = self.device
         # ---- weight packing (one launch for the whole network)
         packs = (PackProb * max(1, len(self.convs)))()
+        packs_eval = (PackProb * max(1, len(self.convs)))()     # eval plan: BatchNorm scale folded into the forward weights
         blk = 0
         for k, cv in enumerate(self.convs):
             cout, cin_real, r, s = cv.weight.shape
@@ -376,12 +378,30 @@ class Net:
             pk.wd = cv.wd.data_ptr() if cv.wd is not None else None
             pk.Cout, pk.Cin, pk.Cin_pad, pk.T = cout, cin_real, cin_pad, t
             pk.blk_begin = blk
+            pk.scale = None
+            cv.folded = cv.bn is not None and cv.bias is None and self.fold_eval_bn
+            cv.wf_eval = torch.empty_like(cv.wf) if cv.folded else cv.wf
+            pe = packs_eval[k]
+            pe.w, pe.wf, pe.wd = cv.weight.data_ptr(), cv.wf_eval.data_ptr(), None
+            pe.Cout, pe.Cin, pe.Cin_pad, pe.T, pe.blk_begin = cout, cin_real, cin_pad, t, blk
+            pe.scale = cv.bn.scale.data_ptr() if cv.folded else None
             blk += -(-(t * cin_pad * cout) // 256)
+        pack_eval_op = None
         if self.convs:
             dpacks = self._dev_struct(packs)
             pack_op = self._op(nv.OP_PACK, ints=(len(self.convs), blk), ptrs=(dpacks,))
             self.fwd_train.add(pack_op, 'pack_weights')
-            self.fwd_eval.add(pack_op, 'pack_weights')
+            # (the eval plan packs after the batched eval-mode affine: its weights depend on the BatchNorm scales)
+            pack_eval_op = self._op(nv.OP_PACK, ints=(len(self.convs), blk), ptrs=(self._dev_struct(packs_eval),))
+        # eval plan: a conv whose only consumer is `out = relu(bn(conv))` writes `out` itself (folded BN + ReLU epilogue)
+        eval_sink, eval_skip = {}, set()
+        if self.fold_eval_bn:
+            for kind_, pay_ in self.nodes:
+                if kind_ == 'fuse':
+                    out_, terms_, relu_ = pay_
+                    if len(terms_) == 1 and isinstance(terms_[0][0], ConvNode) and terms_[0][1] == 0 and terms_[0][0].folded:
+                        eval_sink[id(terms_[0][0])] = (out_, relu_)
+                        eval_skip.add(id(pay_))
         both = (self.fwd_train, self.fwd_eval)
         eval_bns = []
         eval_affine_at = len(self.fwd_eval)      # position of the batched eval-affine record (filled in after the walk)
@@ -416,6 +436,13 @@ class Net:
                     prob_eval = ConvProb.from_buffer_copy(prob)
                     prob_eval.stats = None
                     prob_eval.bnf = None
+                    if cv.folded:              # y = conv(x; w * scale) + shift [, ReLU, written straight into the fuse output]
+                        prob_eval.w = cv.wf_eval.data_ptr()
+                        prob_eval.bias = bn.shift.data_ptr()
+                        sink = eval_sink.get(id(cv))
+                        if sink is not None:
+                            prob_eval.y = sink[0].buf.data_ptr()
+                            prob_eval.relu = 1 if sink[1] else 0
                     self.keep.append(prob_eval)
                     if self.fuse_finalize:
                         # train plan: the conv launch finalises its own BatchNorm statistics (last workgroup), no extra launch
@@ -458,8 +485,17 @@ class Net:
                 op = self._op(nv.OP_FUSE_FWD, ptrs=(C.addressof(fa),))
                 elems = out.N * out.H * out.W * out.C
                 rd = sum((t.y if isinstance(t, ConvNode) else t).buf.numel() for t, _ in terms)
-                for pl in both:
-                    pl.add(op, 'fuse_fwd', 0, 4.0 * (elems + rd))
+                self.fwd_train.add(op, 'fuse_fwd', 0, 4.0 * (elems + rd))
+                if not self.fold_eval_bn:
+                    self.fwd_eval.add(op, 'fuse_fwd', 0, 4.0 * (elems + rd))
+                elif id(pay) not in eval_skip:
+                    fe = FuseArgs.from_buffer_copy(fa)          # BN terms arrive with their affine already applied
+                    for k, (t, _) in enumerate(terms):
+                        if isinstance(t, ConvNode) and t.folded:
+                            fe.scale[k] = None
+                            fe.shift[k] = None
+                    self.keep.append(fe)
+                    self.fwd_eval.add(self._op(nv.OP_FUSE_FWD, ptrs=(C.addressof(fe),)), 'fuse_fwd', 0, 4.0 * (elems + rd))
             elif kind == 'maxpool':
                 x, y, idx = pay
                 op = self._op(nv.OP_MAXPOOL_FWD, ints=(x.N, x.H, x.W, x.C), ptrs=(x.buf, y.buf, idx))
@@ -488,6 +524,11 @@ class Net:
             op.i[10] = 0
             self.fwd_eval.insert(eval_affine_at, op)
             self.fwd_eval.meta.insert(eval_affine_at, {'label': 'bn_eval_affine_batched', 'flops': 0.0, 'bytes': 0.0})
+            eval_affine_at += 1
+        if pack_eval_op is not None:
+            pack_eval_op.i[10] = 0
+            self.fwd_eval.insert(eval_affine_at, pack_eval_op)
+            self.fwd_eval.meta.insert(eval_affine_at, {'label': 'pack_weights', 'flops': 0.0, 'bytes': 0.0})
         if train_backward:
             self._emit_backward()
         self.plan_train = self._freeze(self.fwd_train)

@@ -22,7 +22,7 @@ class ConvProb(C.Structure):
             'Rt', 'St', 'dh0', 'dhs', 'dw0', 'dws', 'w0', 'wrs', 'wss', 'lTI', 'lTH', 'lTW', 'HH', 'HW', 'CK', 'LD',
             'tiles_a', 'tiles_b', 'n_mtiles', 'n_ntiles', 'blk_begin', 'accumulate', 'dma')] + [
         ('x_bytes', C.c_uint), ('w_bytes', C.c_uint), ('magic_spp', C.c_uint), ('mt_r', C.c_int), ('lwn', C.c_int), ('nt', C.c_int),
-        ('magic_hw', C.c_uint), ('magic_hh', C.c_uint), ('tpb', C.c_int), ('wres', C.c_int), ('bnf', c_fp)]
+        ('magic_hw', C.c_uint), ('magic_hh', C.c_uint), ('tpb', C.c_int), ('wres', C.c_int), ('bnf', c_fp), ('relu', C.c_int)]
 
 
 class BnFinalizeArgs(C.Structure):
@@ -47,7 +47,7 @@ class WgradProb(C.Structure):
 
 class PackProb(C.Structure):
     _fields_ = [('w', c_fp), ('wf', c_fp), ('wd', c_fp), ('Cout', C.c_int), ('Cin', C.c_int), ('Cin_pad', C.c_int),
-                ('T', C.c_int), ('blk_begin', C.c_int)]
+                ('T', C.c_int), ('blk_begin', C.c_int), ('scale', c_fp)]
 
 
 class FuseArgs(C.Structure):

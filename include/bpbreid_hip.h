@@ -82,6 +82,7 @@ typedef struct BpbConvProb {
     int tpb;                // consecutive M tiles walked by one workgroup (>= 1); grid = ceil(n_mtiles / tpb) * n_ntiles
     int wres;               // 1: the weight tiles of all Cin/CK chunks stay resident in LDS for the whole workgroup
     const BpbBnFinalizeArgs* bnf;   // optional (device pointer, needs `stats`): fused BatchNorm finalisation
+    int relu;               // y = max(y, 0) in the epilogue (eval plan: conv + folded BatchNorm + ReLU in one launch)
 } BpbConvProb;
 
 /* weight-gradient problem: dW[t][ci][co] = sum_{n,a,b} x[n, a*sa + t/S + ih0, b*sa + t%S + iw0, ci] * dy[n,a,b,co] */
@@ -111,6 +112,7 @@ typedef struct BpbPackProb {
     float* wd;
     int Cout, Cin, Cin_pad, T;
     int blk_begin;
+    const float* scale;   // optional [Cout]: wf is multiplied by scale[co] (eval mode: BatchNorm folded into the weights)
 } BpbPackProb;
 
 /* one BatchNorm of a batched eval-mode affine launch (bpb_bn_eval_affine_batched): scale = gamma / sqrt(rv + eps),
