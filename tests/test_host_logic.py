@@ -35,6 +35,33 @@ def test_struct_layouts_match_the_c_side():
     assert C.sizeof(nv.PlanOp) == 4 + 11 * 4 + 4 * 4 + 2 * 8 + 12 * 8
 
 
+def test_ctypes_mirrors_have_the_c_layout(tmp_path):
+    """Every ctypes Structure in native.py against the C compiler's own layout of include/bpbreid_hip.h: a small C program
+    prints sizeof / offsetof for every field and the numbers must agree (a silent mismatch would scramble launch arguments)."""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('no C compiler')
+    pairs = {'BpbConvProb': nv.ConvProb, 'BpbWgradProb': nv.WgradProb, 'BpbPackProb': nv.PackProb, 'BpbFuseArgs': nv.FuseArgs,
+             'BpbTermBwdArgs': nv.TermBwdArgs, 'BpbBilinearArgs': nv.BilinearArgs, 'BpbBnFinalizeArgs': nv.BnFinalizeArgs,
+             'BpbBnEvalDesc': nv.BnEvalDesc, 'BpbPlanOp': nv.PlanOp}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "bpbreid_hip.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append('printf("%s.sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, *_ in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['return 0; }']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, stdout=subprocess.PIPE).stdout.decode().splitlines())
+    for cname, cls in pairs.items():
+        assert int(got[cname + '.sizeof']) == C.sizeof(cls), cname
+        for fname, *_ in cls._fields_:
+            assert int(got['%s.%s' % (cname, fname)]) == getattr(cls, fname).offset, (cname, fname)
+
+
 def test_choose_tile_minimises_padding():
     assert choose_tile(64, 64, 32, 256) == (1, 8, 32)
     assert choose_tile(64, 8, 4, 256) == (8, 8, 4)
