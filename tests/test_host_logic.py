@@ -180,3 +180,67 @@ def test_state_dict_keys_equal_the_oracle(name):
     b = OracleModel(7, cfg).state_dict()
     assert list(a.keys()) == list(b.keys())
     assert all(a[k].shape == b[k].shape for k in a)
+
+
+def test_launch_plan_stream_invariants():
+    """The recorded plans of a whole HRNet (built on the CPU: planning touches no kernel): stream slots, the hand-off of
+    every weight gradient to its companion stream, the joins, and the branch interleaving of the freeze step."""
+    import torch
+    from bpbreid_amd.backbones import HRNet
+    from bpbreid_amd.graph import Net
+    hr = HRNet((8, 16, 32, 64))
+    for p in hr.parameters():
+        p.grad = torch.zeros_like(p)
+    net = Net(torch.device('cpu'))
+    out = hr.emit(net, net.input_nchw(4, 3, 64, 32))
+    net.finalize(train_backward=True)
+    arr, n, meta = net.plan_bwd
+    ops = [arr[k] for k in range(n)]
+    kinds = [o.kind for o in ops]
+    # (1) freeze re-orders, it never drops or duplicates: same multiset of records as the emission list
+    assert n == len(net.bwd) and sorted(m['label'] for m in meta) == sorted(m['label'] for m in net.bwd.meta)
+    # (2) inside every fork..join region the records of one chain (slot s and its companion s+4) keep their emission order
+    def chain(o):
+        return (o.i[0] if o.kind == nv.OP_DEP else o.i[10]) % 4
+    pos_in_emission = []
+    em_bytes = [bytes(o) for o in net.bwd]
+    used = [False] * len(em_bytes)
+    for o in ops:                                    # match frozen records back to emission positions (first unused equal one)
+        b = bytes(o)
+        j = next(i for i, e in enumerate(em_bytes) if e == b and not used[i])
+        used[j] = True
+        pos_in_emission.append(j)
+    for c in range(4):
+        seq = [p for o, p in zip(ops, pos_in_emission) if o.kind not in (nv.OP_FORK, nv.OP_JOIN) and chain(o) == c]
+        assert seq == sorted(seq), 'chain %d re-ordered' % c
+    # (3) every weight-gradient launch runs on a companion slot (4..7) and is preceded by a DEP from its branch slot
+    pending = set()
+    for o in ops:
+        if o.kind == nv.OP_DEP and o.i[1] >= 4:
+            assert o.i[1] == o.i[0] + 4
+            pending.add(o.i[1])
+        if o.kind in (nv.OP_WGRAD, nv.OP_WGRAD_REDUCE):
+            assert o.i[10] >= 4 and o.i[10] in pending
+        elif o.kind not in (nv.OP_DEP, nv.OP_FORK, nv.OP_JOIN):
+            assert o.i[10] < 4
+    # (4) the plan ends by bringing every companion stream back to the caller's stream
+    tail = [o for o in ops[-8:] if o.kind == nv.OP_DEP and o.i[1] == 0]
+    assert sorted(o.i[0] for o in tail) == sorted(pending)
+    # (5) forks and joins are balanced and never nested
+    depth = 0
+    for kd in kinds:
+        if kd == nv.OP_FORK:
+            depth += 1
+        elif kd == nv.OP_JOIN:
+            depth -= 1
+        assert depth in (0, 1)
+    assert depth == 0
+    # (6) eval plan: no statistics, one batched affine, one pack; train plan: one finalize per BatchNorm
+    earr, en, emeta = net.plan_eval
+    labels = [m['label'] for m in emeta]
+    assert labels.count('bn_eval_affine_batched') == 1 and labels.count('pack_weights') == 1 and 'bn_finalize' not in labels
+    assert labels.index('bn_eval_affine_batched') < labels.index('pack_weights')
+    tlabels = [m['label'] for m in net.plan_train[2]]
+    nbn = sum(1 for cv in net.convs if cv.bn is not None)
+    assert tlabels.count('bn_finalize') == nbn == len(net.convs)
+    assert labels.count('fuse_fwd') < tlabels.count('fuse_fwd')          # single-term fuses are folded into the conv in eval
