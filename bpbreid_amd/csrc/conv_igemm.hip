@@ -22,6 +22,11 @@
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// 24-bit multiply (full rate; v_mul_lo_u32 is quarter rate): exact when both OPERANDS are < 2^24 and the product < 2^32.
+// Used for halo-local coordinates and for (image, row, column) -> pixel index; the pixel index itself may exceed 2^24,
+// so its product with the channel count stays a 32-bit multiply.
+#define M24(a, b) __umul24((unsigned)(a), (unsigned)(b))
+
 __device__ __forceinline__ unsigned bpb_fdiv(unsigned x, unsigned d, unsigned magic)
 {
     return d == 1 ? x : __umulhi(x, magic);
@@ -64,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_igemm_kernel(const BpbConvPro
     for (int mt = 0; mt < MTr; ++mt) {
         const int m = (wm * MTr + mt) * 32 + l31;
         const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
-        pixoff[mt] = (((ti * HH + th * sa) * HWd + tw * sa) * LD) * 4 + (C4 ? 0 : half * 16);
+        pixoff[mt] = (int)M24(M24(M24(ti, HH) + M24(th, sa), HWd) + M24(tw, sa), LD) * 4 + (C4 ? 0 : half * 16);
     }
     const int cout_l = ntile * NTC + wni * NT * 32 + l31;
 
@@ -106,15 +111,15 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_igemm_kernel(const BpbConvPro
     constexpr unsigned DMA_OOB = 0x80000000u;
     auto halo_voff = [&](int idx, int cb, int n0, int a0, int b0) -> unsigned {
         const unsigned hp = bpb_fdiv((unsigned)idx, spp, P.magic_spp);
-        const int v = idx - hp * spp;
+        const int v = idx - (int)M24(hp, spp);
         if (idx >= halo_slots || v >= qn) return DMA_OOB;
         const unsigned t = bpb_fdiv(hp, HWd, P.magic_hw);
-        const int hc = hp - t * HWd;
+        const int hc = hp - M24(t, HWd);
         const unsigned ti = bpb_fdiv(t, HH, P.magic_hh);
-        const int hr = t - ti * HH;
+        const int hr = t - M24(ti, HH);
         const int n = n0 + (int)ti, ih = a0 * sa + hr + P.ih0, iw = b0 * sa + hc + P.iw0;
         if (n < P.N && (unsigned)ih < (unsigned)P.Hi && (unsigned)iw < (unsigned)P.Wi)
-            return ((((unsigned)n * P.Hi + ih) * P.Wi + iw) * Cin + cb + v * 4) * 4u;
+            return ((M24(M24(n, P.Hi) + ih, P.Wi) + iw) * (unsigned)Cin + cb + v * 4) * 4u;   // (pixel index may exceed 2^24)
         return DMA_OOB;
     };
     auto b_voff = [&](int bi, int cb) -> unsigned {
@@ -568,15 +573,15 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_wgrad_kernel(const BpbWgradPr
     };
     auto halo_voff = [&](int idx, int n0, int a0, int b0) -> unsigned {
         const unsigned hp = bpb_fdiv((unsigned)idx, spp, P.magic_spp);
-        const int v = idx - hp * spp;
+        const int v = idx - (int)M24(hp, spp);
         if (idx >= halo_slots || v >= vpp) return 0xFFFFFFF0u;
         const unsigned t = bpb_fdiv(hp, HWd, P.magic_hw);
-        const int hc = hp - t * HWd;
+        const int hc = hp - M24(t, HWd);
         const unsigned ti = bpb_fdiv(t, HH, P.magic_hh);
-        const int hr = t - ti * HH;
+        const int hr = t - M24(ti, HH);
         const int n = n0 + (int)ti, ih = a0 * sa + hr + P.ih0, iw = b0 * sa + hc + P.iw0;
         if (n < P.N && (unsigned)ih < (unsigned)P.Hi && (unsigned)iw < (unsigned)P.Wi)
-            return ((((unsigned)n * P.Hi + ih) * P.Wi + iw) * Cin + ci0 + v * 4) * 4u;
+            return ((M24(M24(n, P.Hi) + ih, P.Wi) + iw) * (unsigned)Cin + ci0 + v * 4) * 4u;
         return 0xFFFFFFF0u;
     };
     auto dy_voff = [&](int idx, int n0, int a0, int b0) -> unsigned {
@@ -585,7 +590,7 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_wgrad_kernel(const BpbWgradPr
         const int n = n0 + ti, a = a0 + th, b = b0 + tw;
         const int co = co0 + v * 4;
         if (n < P.N && a < P.A && b < P.B && co < Cout)   // Cout % 4 == 0
-            return ((((unsigned)n * P.A + a) * P.B + b) * Cout + co) * 4u;
+            return ((M24(M24(n, P.A) + a, P.B) + b) * (unsigned)Cout + co) * 4u;
         return 0xFFFFFFF0u;
     };
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)P.x, 0, (int)P.x_bytes, 0x00020000);
@@ -625,7 +630,7 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_wgrad_kernel(const BpbWgradPr
     for (int ks = 0; ks < 16; ++ks) {
         const int m = wave * 32 + ks * 2 + half;
         const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
-        xo[ks] = (((ti * HH + th * sa) * HWd + tw * sa) * LD + l31) * 4;
+        xo[ks] = (int)(M24(M24(M24(ti, HH) + M24(th, sa), HWd) + M24(tw, sa), LD) + l31) * 4;
         mrow[ks] = m * LDY + l31;
     }
     if (dma && mt_begin < mt_end) dma_issue(mt_begin, 0);
