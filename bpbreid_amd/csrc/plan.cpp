@@ -110,23 +110,31 @@ extern "C" int bpb_plan_run(const BpbPlanOp* ops, int nops, hipStream_t stream)
     return 0;
 }
 
-// Measurement variant: brackets every op with HIP events ON THE SAME STREAM and returns the elapsed
-// milliseconds per op in ms_out[nops] (synchronises at the end).  Used by bench.py for the live per-kernel
-// durations behind the roofline numbers; never used on the training path.
+// Measurement variant: brackets every record with HIP events ON THE SAME STREAM and returns the elapsed milliseconds per
+// launch in ms_out[nops] (synchronises at the end).  Each record is launched BPB_TIMED_REPS times back to back between its
+// two events and the time divided: the fixed event / launch gap (~3 us, as large as some of the kernels) is amortised, so
+// the figure is the kernel's own duration -- what `rocprofv3 --kernel-trace` reports for it.  Replaying a record repeats
+// its side effects (accumulating launches, running statistics): MEASUREMENT ONLY, never on the training path; bench.py
+// calls it after the timed region.
+#define BPB_TIMED_REPS 3
 extern "C" int bpb_plan_run_timed(const BpbPlanOp* ops, int nops, hipStream_t stream, float* ms_out)
 {
-    std::vector<hipEvent_t> ev(nops + 1);
+    std::vector<hipEvent_t> ev(2 * (size_t)nops);
     for (auto& e : ev)
         if (hipEventCreate(&e) != hipSuccess) return bpb_set_error(1, "bpb_plan_run_timed: hipEventCreate failed");
-    (void)hipEventRecord(ev[0], stream);
     int rc = 0;
-    for (int k = 0; k < nops && rc == 0; ++k) {     // everything on ONE stream: fork/join records are no-ops here
-        if (ops[k].kind != BPB_OP_FORK && ops[k].kind != BPB_OP_JOIN && ops[k].kind != BPB_OP_DEP) rc = run_one(ops[k], k, stream);
-        (void)hipEventRecord(ev[k + 1], stream);
+    for (int k = 0; k < nops && rc == 0; ++k) {     // everything on ONE stream: fork / join / dep records are no-ops here
+        const bool launch = ops[k].kind != BPB_OP_FORK && ops[k].kind != BPB_OP_JOIN && ops[k].kind != BPB_OP_DEP;
+        (void)hipEventRecord(ev[2 * k], stream);
+        for (int r = 0; r < BPB_TIMED_REPS && launch && rc == 0; ++r) rc = run_one(ops[k], k, stream);
+        (void)hipEventRecord(ev[2 * k + 1], stream);
     }
     (void)hipStreamSynchronize(stream);
     if (rc == 0)
-        for (int k = 0; k < nops; ++k) (void)hipEventElapsedTime(&ms_out[k], ev[k], ev[k + 1]);
+        for (int k = 0; k < nops; ++k) {
+            (void)hipEventElapsedTime(&ms_out[k], ev[2 * k], ev[2 * k + 1]);
+            ms_out[k] /= (float)BPB_TIMED_REPS;
+        }
     for (auto& e : ev) (void)hipEventDestroy(e);
     return rc;
 }
