@@ -75,6 +75,8 @@ class Act:
         self.grad = None
         self.needs_grad = True
         self._grad_written = False
+        self.consumers = []      # (fork region, stream slot) of every node that reads this tensor
+        self.grad_parts = {}     # slot -> partial gradient buffer (tensors read from several slots of one region)
 
     def ensure_grad(self, net):
         if self.grad is None:
@@ -114,6 +116,9 @@ class Net:
         self.convs = []
         self.fwd_train, self.fwd_eval, self.bwd = PlanList(), PlanList(), PlanList()
         self.cur_slot = 0          # stream slot of the nodes being recorded (branch-level concurrency)
+        self.cur_region = 0        # 0 outside fork..join, otherwise the ordinal of the enclosing fork
+        self._nregions = 0
+        self.node_regions = []
         self.debug_convs = []      # (ConvProb, x, packed w, y) -- lets the CPU tests emulate the descriptors
         self.debug_wgrads = []     # (WgradProb, ConvNode)
         # Several M tiles per workgroup (BpbConvProb.tpb/wres) is implemented and tested, but measured slower than two
@@ -133,17 +138,21 @@ class Net:
     def _node(self, kind, payload):
         self.nodes.append((kind, payload))
         self.node_slots.append(self.cur_slot)
+        self.node_regions.append(self.cur_region)
 
     def fork(self, nslots):
         """Branches recorded with set_slot(1..nslots-1) may run concurrently with slot 0 until the matching join()."""
         assert self.cur_slot == 0 and 1 <= nslots <= 4
         if nslots > 1:
+            self._nregions += 1
+            self.cur_region = self._nregions
             self._node('fork', (1 << (nslots - 1)) - 1)
 
     def join(self, nslots):
         assert self.cur_slot == 0
         if nslots > 1:
             self._node('join', (1 << (nslots - 1)) - 1)
+            self.cur_region = 0
 
     def set_slot(self, slot):
         self.cur_slot = slot
@@ -166,6 +175,7 @@ class Net:
         y = Act(self, x.N, ho, wo, cout)
         bnst = BNState(self, cout, *bn) if bn is not None else None
         node = ConvNode(x, y, weight, bias, bnst, r, s, stride, pad, cin_real)
+        x.consumers.append((self.cur_region, self.cur_slot))
         self._node('conv', node)
         self.convs.append(node)
         return node
@@ -178,6 +188,7 @@ class Net:
         for t, up in terms:
             a = t.y if isinstance(t, ConvNode) else t
             assert (a.H << up, a.W << up, a.C) == (out.H, out.W, out.C), 'fuse: term shape mismatch'
+            a.consumers.append((self.cur_region, self.cur_slot))
         self._node('fuse', (out, list(terms), bool(relu)))
         return out
 
@@ -185,6 +196,7 @@ class Net:
         ho, wo = (x.H + 2 - 3) // 2 + 1, (x.W + 2 - 3) // 2 + 1
         y = Act(self, x.N, ho, wo, x.C)
         idx = torch.empty(x.N, ho, wo, x.C, device=self.device, dtype=torch.uint8)
+        x.consumers.append((self.cur_region, self.cur_slot))
         self._node('maxpool', (x, y, idx))
         return y
 
@@ -192,6 +204,8 @@ class Net:
         """hrnet.py:568-573: upsample every map to the first one's resolution and concatenate channels."""
         a0 = srcs[0]
         out = Act(self, a0.N, a0.H, a0.W, sum(a.C for a in srcs))
+        for a in srcs:
+            a.consumers.append((self.cur_region, self.cur_slot))
         self._node('concat', (out, list(srcs)))
         return out
 
@@ -593,12 +607,16 @@ class Net:
         bwd = self.bwd
         # shared split-K workspace for weight gradients (sized while emitting)
         ws_requests = []
-        for (kind, pay), slot in zip(reversed(self.nodes), reversed(self.node_slots)):
+        self._part_acts = []           # tensors whose gradient is being collected in per-slot partial buffers
+        for (kind, pay), slot, region in zip(reversed(self.nodes), reversed(self.node_slots), reversed(self.node_regions)):
             bwd.slot = slot
             self._bwd_slot = slot
+            self._bwd_region = region
             if kind in ('fork', 'join'):       # the backward of a join is a fork and vice versa
                 bwd.slot = 0
                 bwd.add(self._op(nv.OP_JOIN if kind == 'fork' else nv.OP_FORK, ints=(pay,)), 'join' if kind == 'fork' else 'fork')
+                if kind == 'fork':
+                    self._flush_grad_parts()       # the region's streams are joined: sum the per-slot partial gradients
                 continue
             if kind == 'concat':
                 out, srcs = pay
@@ -643,8 +661,8 @@ class Net:
                         if up == 0 and self.merge_identity:
                             for k2, (t2, up2) in enumerate(terms):
                                 if k2 not in merged and not isinstance(t2, ConvNode) and up2 == 0 and t2.needs_grad:
-                                    ta.dsrc2 = t2.ensure_grad(self).data_ptr()
-                                    ta.accumulate2 = t2.take_acc_flag()
+                                    tgt2, ta.accumulate2 = self._grad_target(t2)
+                                    ta.dsrc2 = tgt2.data_ptr()
                                     merged.add(k2)
                                     extra = 4.0 * t2.buf.numel()
                                     break
@@ -663,8 +681,8 @@ class Net:
                     else:
                         if not a.needs_grad:
                             continue
-                        ta.dsrc = a.ensure_grad(self).data_ptr()
-                        ta.accumulate = a.take_acc_flag()
+                        tgt, ta.accumulate = self._grad_target(a)
+                        ta.dsrc = tgt.data_ptr()
                         bwd.add(self._op(nv.OP_TERM_BWD, ints=(0, 0), ptrs=(C.addressof(ta),)), 'identity_bwd', 0,
                                 4.0 * a.buf.numel() * (1 + 2 * 4 ** up))
             elif kind == 'maxpool':
@@ -694,6 +712,47 @@ class Net:
 
     _wgrad_descs = None
     _pending_reduce = None
+
+    def _grad_target(self, a):
+        """(buffer, accumulate flag) for a gradient contribution to tensor `a` from the node being planned.  A tensor read
+        from several stream slots of ONE fork region (a branch output feeding the exchange paths of every target) would get
+        concurrent read-modify-write accumulations: each slot then writes its own partial buffer and the partials are summed
+        once, in a fixed order, right after the region's join (deterministic; the traffic equals the accumulation's)."""
+        region = self._bwd_region
+        slots = sorted({s_ for r_, s_ in a.consumers if r_ == region})
+        if region == 0 or len(slots) <= 1:
+            return a.ensure_grad(self), a.take_acc_flag()
+        part = a.grad_parts.get(self._bwd_slot)
+        if part is None:
+            part = torch.empty_like(a.buf)
+            a.grad_parts[self._bwd_slot] = part
+            if a not in self._part_acts:
+                self._part_acts.append(a)
+            return part, 0
+        return part, 1
+
+    def _flush_grad_parts(self):
+        for a in self._part_acts:
+            parts = [a.grad_parts[s_] for s_ in sorted(a.grad_parts)]
+            g = a.ensure_grad(self)
+            srcs = ([g] if a.take_acc_flag() else []) + parts
+            assert len(srcs) <= 4, 'more than four gradient partials for one tensor'
+            fa = FuseArgs()
+            fa.out = g.data_ptr()
+            for k, t in enumerate(srcs):
+                fa.src[k] = t.data_ptr()
+                fa.scale[k] = None
+                fa.shift[k] = None
+                fa.up[k] = 0
+            fa.nterms = len(srcs)
+            fa.N, fa.H, fa.W, fa.C = a.N, a.H, a.W, a.C
+            fa.relu = 0
+            fa.magic_w, fa.magic_h = magic(a.W), magic(a.H)
+            self.keep += [fa, parts]
+            self.bwd.slot = 0
+            self.bwd.add(self._op(nv.OP_FUSE_FWD, ptrs=(C.addressof(fa),)), 'grad_parts_sum', 0, 4.0 * a.buf.numel() * (len(srcs) + 1))
+            a.grad_parts = {}
+        self._part_acts = []
 
     def _emit_conv_backward(self, cv, ws_requests):
         if self._wgrad_descs is None:
@@ -767,8 +826,7 @@ class Net:
         # ---- data gradient
         if not x.needs_grad:
             return
-        gx = x.ensure_grad(self)
-        acc = x.take_acc_flag()
+        gx, acc = self._grad_target(x)
         st, pad = cv.stride, cv.pad
         for ph in range(st):
             for pw in range(st):
