@@ -113,13 +113,25 @@ class MultiResModule(nn.Module):
             rows.append(nn.ModuleList(row))
         self.fuse_layers = nn.ModuleList(rows)
 
-    def emit(self, net, xs):
-        xs = _emit_parallel_chains(net, self.branches, xs)
+    def emit(self, net, xs, first=True, last=True):
+        """`first` / `last`: position of the module in its stage.  The branch chains of a module run on the stream slots its
+        predecessor's exchange step left open (target i's fused output is produced on slot i and feeds branch i only), so a
+        stage has ONE stream barrier per module -- between the branches and the exchange, where every target needs every
+        branch -- instead of two."""
+        nb = len(self.fuse_layers)
+        if first:
+            net.fork(nb)
+        ys = []
+        for i, (chain, x) in enumerate(zip(self.branches, xs)):
+            net.set_slot(i)
+            ys.append(_emit_chain(net, chain, x))
+        net.set_slot(0)
+        net.join(nb)
+        xs = ys
         # Exchange step.  Down-paths of different targets share nothing, up-paths are 1x1 conv + BN whose nearest upsample is
         # folded into the fuse read (no upsampled tensor is ever written).  The paths into target i (up to three small convs
         # each, 16 convs + 24 BatchNorm/fuse launches in a 4-branch module) and its final fuse are recorded on stream slot i:
         # recorded on one stream they were ~10 ms of strictly serial small launches per train step.
-        nb = len(self.fuse_layers)
         net.fork(nb)
         outs = []
         for i, row in enumerate(self.fuse_layers):
@@ -141,7 +153,8 @@ class MultiResModule(nn.Module):
                             terms.append((c, 0))
             outs.append(net.fuse(terms, relu=True))
         net.set_slot(0)
-        net.join(nb)
+        if last:
+            net.join(nb)
         return outs
 
 
@@ -200,8 +213,9 @@ class HRNet(nn.Module):
                     for st in t:
                         src = net.fuse([(_emit_cb(net, src, st[0], st[1]), 0)], relu=True)
                 xs.append(src)
-            for mod in getattr(self, 'stage%d' % (s + 2)):
-                xs = mod.emit(net, xs)
+            stage = list(getattr(self, 'stage%d' % (s + 2)))
+            for m, mod in enumerate(stage):
+                xs = mod.emit(net, xs, first=m == 0, last=m == len(stage) - 1)
             ys = xs
         ys = _emit_parallel_chains(net, self.incre_modules, ys)
         return net.concat_bilinear(ys)
