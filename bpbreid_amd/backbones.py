@@ -217,8 +217,20 @@ class HRNet(nn.Module):
             for m, mod in enumerate(stage):
                 xs = mod.emit(net, xs, first=m == 0, last=m == len(stage) - 1)
             ys = xs
-        ys = _emit_parallel_chains(net, self.incre_modules, ys)
-        return net.concat_bilinear(ys)
+        # head: the channel-increasing bottleneck of every branch and its bilinear up-sampling into the concatenated map
+        # (hrnet.py:565-573) run on the branch's own stream slot
+        out = net.concat_begin(ys[0].N, ys[0].H, ys[0].W, self.layers_out_channels)
+        n = len(self.incre_modules)
+        net.fork(n)
+        c0 = 0
+        for i, (chain, y) in enumerate(zip(self.incre_modules, ys)):
+            net.set_slot(i)
+            y = _emit_chain(net, chain, y)
+            net.concat_part(out, y, c0)
+            c0 += y.C
+        net.set_slot(0)
+        net.join(n)
+        return out
 
 
 class ResNet50(nn.Module):

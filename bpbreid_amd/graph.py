@@ -200,13 +200,22 @@ class Net:
         self._node('maxpool', (x, y, idx))
         return y
 
+    def concat_begin(self, n, h, w, c_total):
+        """Output tensor of a channel concatenation whose sources are added one by one with concat_part (each on the stream
+        slot that produced the source, so the up-sampling launches of the branches run side by side)."""
+        return Act(self, n, h, w, c_total)
+
+    def concat_part(self, out, a, c0):
+        a.consumers.append((self.cur_region, self.cur_slot))
+        self._node('concat', (out, [a], c0))
+
     def concat_bilinear(self, srcs):
         """hrnet.py:568-573: upsample every map to the first one's resolution and concatenate channels."""
         a0 = srcs[0]
         out = Act(self, a0.N, a0.H, a0.W, sum(a.C for a in srcs))
         for a in srcs:
             a.consumers.append((self.cur_region, self.cur_slot))
-        self._node('concat', (out, list(srcs)))
+        self._node('concat', (out, list(srcs), 0))
         return out
 
     # ------------------------------------------------------------------ plan emission helpers
@@ -516,8 +525,7 @@ class Net:
                 for pl in both:
                     pl.add(op, 'maxpool_fwd', 0, 4.0 * (x.buf.numel() + 1.25 * y.buf.numel()))
             elif kind == 'concat':
-                out, srcs = pay
-                c0 = 0
+                out, srcs, c0 = pay
                 for a in srcs:
                     ba = self._bilinear_args(a.buf, out.buf, a, out, c0)
                     op = self._op(nv.OP_BILINEAR_FWD, ptrs=(C.addressof(ba),))
@@ -619,8 +627,7 @@ class Net:
                     self._flush_grad_parts()       # the region's streams are joined: sum the per-slot partial gradients
                 continue
             if kind == 'concat':
-                out, srcs = pay
-                c0 = 0
+                out, srcs, c0 = pay
                 offs = []
                 for a in srcs:
                     offs.append(c0)
