@@ -9,15 +9,15 @@
 // cannot hold the tolerance.  The roofline for these kernels is therefore
 // the fp32-matrix peak, 157.3 TFLOP/s.
 //
-// Data layout: activations NHWC fp32.  One workgroup = 4 waves = a 256-pixel x (32*NT)-channel
-// output tile.  The (TI x TH x TW) pixel tile's input halo for a chunk of CK input channels is
-// staged once in LDS ([halo pixel][CK + 4 pad] -> conflict-free 16-byte fragment reads) and
-// reused by every filter tap (9x reuse for 3x3).  MFMA operand packing: for one 16-byte LDS read
-// lanes 0-31 hold channels c..c+3 of pixel (lane&31) and lanes 32-63 channels c+4..c+7, which is
-// exactly the A fragment of four consecutive 32x32x2 MFMAs; the weights are pre-packed
-// [tap][Cin/4][Cout][4] so that the matching B fragments are one coalesced 16-byte global load
-// (weights are L2/L1 resident; they never touch LDS).  Operands for k-group j+1 are fetched
-// into registers before the MFMAs of k-group j issue.
+// Data layout: activations NHWC fp32.  One workgroup = 4 waves = a (4 * MT * 32 >> lwn)-pixel x ((32 * NT) << lwn)-channel
+// output tile (MT, NT template parameters, lwn per problem).  Per chunk of CK input channels the (TI x TH x TW) pixel
+// tile's input halo ([halo pixel][CK + 4 pad] -> conflict-free 16-byte fragment reads) and the weight tile
+// ([tap][CK/4][N tile][4], from the pre-packed [tap][Cin/4][Cout][4] array) are brought into LDS by buffer_load ... lds
+// DMA, double-buffered against the MFMA loop of the previous chunk; the halo is reused by every filter tap (9x for 3x3).
+// MFMA operand packing: for one 16-byte LDS read lanes 0-31 hold channels c..c+3 of pixel (lane&31) and lanes 32-63
+// channels c+4..c+7, which is exactly the A fragment of four consecutive 32x32x2 MFMAs (B likewise); the reads of
+// k-group j+1 are issued before the MFMAs of k-group j.  DESIGN.md section 4 has the full anatomy and section 5 the
+// measurements (what bounds the kernel, what was tried).
 #include "bpb_common.h"
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
