@@ -4,8 +4,8 @@
 // cosine distance [P,Q,G], pair mask q_vis[p,q] * g_vis[p,g] (sqrt for continuous scores, :199), masked mean /
 // max over parts with -1 for pairs without a common visible part, then -1 -> max+1 (:171-176, :214-216).
 // The reference loops over gallery chunks of 500 with a .cpu() per chunk; here one launch covers a gallery
-// shard: a 64x64 (query, gallery) tile runs the P batched GEMMs back to back on the fp32 MFMA pipe and
-// folds each part's distance straight into the masked sums in registers.
+// shard: a 128x128 (query, gallery) tile (64x64 in the generic fallback kernel) runs the P batched GEMMs back to back
+// on the fp32 MFMA pipe and folds each part's distance straight into the masked sum / max in registers.
 #include "bpb_common.h"
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)

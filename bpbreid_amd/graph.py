@@ -3,7 +3,10 @@
 The reference executes the backbone as ~650 nn.Module calls per forward and lets autograd replay them
 (torchreid/models/hrnet.py:532-576, resnet.py:342-358).  Here the network is *compiled once* for a
 batch shape into three flat arrays of launch records (train forward, eval forward, backward) over
-pre-allocated NHWC buffers in HBM; running it is one C call (`bpb_plan_run`).
+pre-allocated NHWC buffers in HBM; running it is one C call (`bpb_plan_run`).  Records carry a stream slot: the
+branches of an HRNet module, the paths of its exchange step and the head's up-sampling are recorded on slots 0..3
+(fork / join), the weight gradient of every convolution on the companion slot 4..7 of its branch (DEP), so that the
+executor spreads independent chains over HIP streams; `_freeze` interleaves the chains in issue order.
 
 Graph vocabulary (all tensors NHWC fp32):
     conv      raw convolution output + per-tile BatchNorm partial sums (conv_igemm.hip)
