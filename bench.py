@@ -46,6 +46,8 @@ def parse():
                          'the ROCm graph executor serialises more of the branch / weight-gradient streams)')
     ap.add_argument('--dist-backend', default='nccl', help="'nccl' (= RCCL over xGMI; the default) or 'gloo' (functional check of the "
                     "multi-process path when the ranks have to share one GPU)")
+    ap.add_argument('--dump-plan-timing', default='', help='write the per-record isolated timings of the forward and backward '
+                    'plans (label, kind, stream slot, ms) to this JSON file (input of tools/critical_path.py)')
     ap.add_argument('--same-data', action='store_true', help=argparse.SUPPRESS)     # tests: every rank gets rank 0's batch
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     return ap.parse_args()
@@ -129,6 +131,18 @@ def pmc_traffic(sym):
     if not row:
         return {'traffic': None}
     return {'traffic': row['hbm_bytes_per_launch'], 'traffic_source': 'profiles/r01_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)'}
+
+
+def dump_plan_timing(plan, path):
+    net = plan.net
+    out = {}
+    for name, pl in (('forward', net.plan_train), ('backward', net.plan_bwd)):
+        arr, n, meta = pl
+        rows = net.run_timed(pl)
+        out[name] = [{'label': m['label'], 'kind': int(arr[k].kind), 'slot': int(arr[k].i[10]), 'i0': int(arr[k].i[0]),
+                      'i1': int(arr[k].i[1]), 'ms': float(ms), 'flops': m['flops'], 'bytes': m['bytes']}
+                     for k, (m, ms) in enumerate(rows)]
+    json.dump(out, open(path, 'w'))
 
 
 def roofline(model, plan):
@@ -246,6 +260,8 @@ def main():
                    'parallelism': 'dp%d' % world, 'global_batch': args.batch * world, 'final_loss': final_loss,
                    'host_enqueue_ms_per_step': 1e3 * host_enqueue / args.steps, 'launch_mode': mode},
     }
+    if rank == 0 and args.dump_plan_timing:
+        dump_plan_timing(next(iter(model._plans.values())), args.dump_plan_timing)
     if rank == 0 and not args.no_roofline:                  # per-GPU figure (the plan of this rank), any world size
         plan = next(iter(model._plans.values()))
         result['roofline'] = roofline(model, plan)
