@@ -42,7 +42,7 @@ def parse():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=16)
     ap.add_argument('--graph', type=int, default=0,
-                    help='1: replay the step from one hipGraph (exact, but measured 5 %% slower than eager multi-stream launches: '
+                    help='1: replay the step from one hipGraph (exact, but measured 10 %% slower than eager multi-stream launches: '
                          'the ROCm graph executor serialises more of the branch / weight-gradient streams)')
     ap.add_argument('--dist-backend', default='nccl', help="'nccl' (= RCCL over xGMI; the default) or 'gloo' (functional check of the "
                     "multi-process path when the ranks have to share one GPU)")
