@@ -19,6 +19,19 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def source_id():
+    """Content hash of the kernel sources (csrc/ + the C-ABI header): stamps measurement files (profiles/*_pmc_hbm.json) so that
+    a figure taken from another build is recognised as stale (the GPU box has no .git to ask for a commit hash)."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted([os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, 'bpb_common.h'),
+                                                                    os.path.join(HERE, '..', 'include', 'bpbreid_hip.h')]):
+        if os.path.exists(path):
+            h.update(os.path.basename(path).encode())
+            h.update(open(path, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=True):
     """Compile every HIP/C++ source into one shared library.  Objects are built in parallel."""
     if not force and not _stale():

@@ -362,16 +362,18 @@ __global__ __launch_bounds__(256) void bpb_visibility_kernel(const float* __rest
 }
 
 // pooled[n][j][c] = (sum over chunks of part) * norm_j ;  j: 0 global (1/HW), 1 fg (1/HW), 2 bg (1/HW),
-// 3.. parts: 1 / clamp(sum_p m_j, 1e-6)  (bpbreid.py:498-501).  Also saves zinv[n][j] = norm_j and the flag
-// `clamped` for the backward.  Deterministic fixed-order sum.
+// 3.. parts: 1 / clamp(sum_p m_j, 1e-6)  (pooling = 'gwap', bpbreid.py:490-503) or 1/HW (pooling = 'gap': the
+// GlobalAveragePoolingHead of bpbreid.py:432-441, :485-486 -- the mean of mask * feature over ALL pixels).  Also saves
+// zinv[n][j] = norm_j for the backward; a NEGATIVE sign marks "the norm does not depend on the mask" (active clamp, or gap):
+// the backward then drops the -S/Z^2 term.  Deterministic fixed-order sum.
 __global__ __launch_bounds__(256) void bpb_pool_finalize_kernel(const float* __restrict__ part, const float* __restrict__ pm,
                                                                 float* __restrict__ pooled, float* __restrict__ zinv,
-                                                                int nchunks, int J, int HW, int C)
+                                                                int nchunks, int J, int HW, int C, int parts_gap)
 {
     __shared__ float red[256];
     const int n = blockIdx.y, j = blockIdx.x;
     float norm;
-    if (j < 3) {
+    if (j < 3 || parts_gap) {
         norm = 1.f / (float)HW;
     } else {
         float s = 0.f;
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(256) void bpb_pool_finalize_kernel(const float* __r
         }
         norm = 1.f / fmaxf(red[0], 1e-6f);
     }
-    if (threadIdx.x == 0) zinv[(long)n * J + j] = (j >= 3 && norm >= 1e6f) ? -norm : norm;   // sign marks an active clamp
+    if (threadIdx.x == 0) zinv[(long)n * J + j] = (j >= 3 && (norm >= 1e6f || parts_gap)) ? -norm : norm;
     for (int c = threadIdx.x; c < C; c += 256) {
         float s = 0.f;
         for (int q = 0; q < nchunks; ++q) s += part[(((long)n * nchunks + q) * J + j) * C + c];
@@ -806,9 +808,10 @@ int bpb_visibility(const float* probs, const unsigned char* argcls, float* vis, 
 }
 
 int bpb_pool_finalize(const float* part, const float* pm, float* pooled, float* zinv, int N, int nchunks, int J, int HW,
-                      int C, hipStream_t stream)
+                      int C, int parts_gap, hipStream_t stream)
 {
-    hipLaunchKernelGGL(bpb_pool_finalize_kernel, dim3(J, N), dim3(256), 0, stream, part, pm, pooled, zinv, nchunks, J, HW, C);
+    hipLaunchKernelGGL(bpb_pool_finalize_kernel, dim3(J, N), dim3(256), 0, stream, part, pm, pooled, zinv, nchunks, J, HW, C,
+                       parts_gap);
     BPB_LAUNCH_OK();
     return 0;
 }

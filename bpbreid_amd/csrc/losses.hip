@@ -163,6 +163,7 @@ __global__ __launch_bounds__(256) void bpb_pixel_ce_kernel(const float* __restri
     const int HW = H * W;
     const long total = (long)N * HW;
     float lsum = 0.f, asum = 0.f;
+    bool bad = false;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
         const long n = i / HW;
         const int p = (int)(i - n * HW), h = p / W, w = p - h * W;
@@ -172,7 +173,11 @@ __global__ __launch_bounds__(256) void bpb_pixel_ce_kernel(const float* __restri
         const float lh1 = fh - h0, lw1 = fw - w0, lh0 = 1.f - lh1, lw0 = 1.f - lw1;
         int y = 0;
         if (targets) {   // the reference engine's call form: int64 [N][H][W] part indices (body_part_attention_loss.py:31-52)
-            y = (int)targets[i];
+            // a label outside [0, K1) (an ignore index, a mask with more parts than the model) raises in the reference
+            // (nn.CrossEntropyLoss); without a host sync the loud equivalent is a NaN loss and NaN gradients for the batch
+            const long yt = targets[i];
+            bad = bad || yt < 0 || yt >= K1;
+            y = (yt < 0 || yt >= K1) ? 0 : (int)yt;
         } else {
             float best = -INFINITY;
             for (int k = 0; k < K1; ++k) {
@@ -196,9 +201,10 @@ __global__ __launch_bounds__(256) void bpb_pixel_ce_kernel(const float* __restri
         if (dscores)
             for (int k = 0; k < K1; ++k) {
                 const float t = (k == y ? 1.f - eps : 0.f) + eps / (float)K1;
-                dscores[(n * K1 + k) * HW + p] = (expf(l[k] - lse) - t) / (float)total;
+                dscores[(n * K1 + k) * HW + p] = bad ? NAN : (expf(l[k] - lse) - t) / (float)total;
             }
     }
+    if (bad) lsum = NAN;
     const float bl = block_sum(lsum, red), ba = block_sum(asum, red);
     if (threadIdx.x == 0) {
         partial[blockIdx.x * 2 + 0] = (double)bl;

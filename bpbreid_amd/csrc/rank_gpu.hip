@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void rk_query_kernel(const float* __restrict__
         const bool same_cam = g < G && g_cam[g] == qc;
         const int is_m = (same_pid && !same_cam) ? 1 : 0;
         const unsigned long long kb = __ballot(g < G && !(same_pid && same_cam));
-        if ((threadIdx.x & 63) == 0) keptbits[g >> 6] = kb;              // (g of lane 0 is a multiple of 64)
+        if ((threadIdx.x & 63) == 0 && g < G) keptbits[g >> 6] = kb;     // (g of lane 0 is a multiple of 64; the table has ceil(G/64) words)
         red[threadIdx.x] = is_m;
         __syncthreads();
         for (int o = 1; o < 256; o <<= 1) {

@@ -106,13 +106,26 @@ def sharded_part_distance(qf, gf_local, qf_parts_visibility=None, gf_local_parts
                 parts[parts == -1] = vmax + 1
     if world == 1:
         return d, parts
-    sizes = torch.zeros(world, dtype=torch.int64, device=d.device)
-    sizes[dist.get_rank(group)] = d.shape[1]
+    return all_gather_cat(d, dim=1, group=group), parts
+
+
+def all_gather_cat(t, dim=0, group=None):
+    """Concatenation along `dim` of the (differently sized along `dim`) tensors `t` of all ranks, identical on every rank.
+    One size all-reduce + one all-gather of blocks padded to the largest shard.  RCCL moves device tensors directly; gloo
+    (CPU tests, functional checks with ranks sharing a GPU) has no device all-gather: the block is staged through the host."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return t
+    staged = t.is_cuda and dist.get_backend(group) == 'gloo'
+    x = t.movedim(dim, 0).contiguous()
+    x = x.cpu() if staged else x
+    sizes = torch.zeros(world, dtype=torch.int64, device=x.device)
+    sizes[dist.get_rank(group)] = x.shape[0]
     dist.all_reduce(sizes, group=group)
-    gmax = int(sizes.max())
-    pad = torch.zeros(d.shape[0], gmax, dtype=d.dtype, device=d.device)     # all_gather needs equal shapes
-    pad[:, :d.shape[1]] = d
+    sizes = sizes.tolist()
+    pad = torch.zeros((max(sizes),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)     # all_gather needs equal shapes
+    pad[:x.shape[0]] = x
     blocks = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(blocks, pad, group=group)
-    full = torch.cat([b[:, :int(n)] for b, n in zip(blocks, sizes.tolist())], dim=1)
-    return full, parts
+    full = torch.cat([b[:int(n)] for b, n in zip(blocks, sizes)], dim=0)
+    return full.to(t.device).movedim(0, dim).contiguous()

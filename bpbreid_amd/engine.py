@@ -15,7 +15,7 @@ import torch
 from . import native as nv
 from .distributed import GradAllReducer
 from .losses import GiLtLoss, BodyPartAttentionLoss
-from .metrics import compute_distance_matrix_using_bp_features, evaluate_rank, re_ranking
+from .metrics import compute_distance_matrix_using_bp_features, evaluate_rank, part_distance_raw, re_ranking
 from .model import bn_correspondants, PIXELS
 from .optim import FusedAdam
 
@@ -108,16 +108,29 @@ class ImagePartBasedEngine:
 
     # ------------------------------------------------------------------ hipGraph replay of the whole step
     def capture_step(self, data, warmup=3):
-        """Record one full train step (forward, losses, backward, [all-reduce], Adam) into a hipGraph.
+        """Record one full train step (forward, losses, backward, [bucketed RCCL all-reduce], Adam) into a hipGraph.
+        On a distributed engine the all-reduce launches are captured with the step (RCCL supports stream capture: the
+        collectives become graph nodes on their own branch, forked where the backward plan hands a bucket over and joined
+        before the Adam launch) -- every rank must capture and replay the same number of times.
 
         Returns `replay(new_data=None) -> (loss, loss_summary)`: copies `new_data` into the captured input buffers (if given)
         and replays the graph -- no Python, no launch-argument marshalling, one host call per step.  Capturing does not train:
         the warm-up iterations that hipGraph capture needs run on a snapshot (parameters, BatchNorm buffers, Adam moments and
         step counter are restored afterwards).  The learning rate and Adam's step counter live in device memory
         (FusedAdam.lr_dev / step_dev), so an LR scheduler keeps working under replay without re-capturing."""
+        if not isinstance(self.optimizer, FusedAdam):
+            # a torch.optim optimizer keeps its step counter / moments outside the arenas: the warm-up iterations would advance
+            # them while the parameters are rolled back (and plain torch.optim.Adam is not capturable)
+            raise nv.NativeError('capture_step needs the FusedAdam optimizer (its whole state is snapshotted and restored); '
+                                 'got %s' % type(self.optimizer).__name__)
+        if self.distributed:
+            import torch.distributed as dist
+            if dist.is_initialized() and dist.get_backend(self.process_group) != 'nccl':
+                raise nv.NativeError('capture_step on a distributed engine needs the RCCL backend ("nccl"): %s collectives '
+                                     'cannot be captured into a hipGraph' % dist.get_backend(self.process_group))
         imgs, masks, pids, _ = self.parse_data_for_train(data)
         static = {'image': imgs.clone(), 'mask': masks.clone() if masks is not None else None, 'pid': pids.clone()}
-        fused = isinstance(self.optimizer, FusedAdam)
+        fused = True
         arena = self.model.arena()
         if fused:
             self.optimizer._state()
@@ -189,11 +202,30 @@ class ImagePartBasedEngine:
             msk.append(pm if pm.dim() == 4 else pm.unsqueeze(1))
         return torch.cat(embs, dim=1), torch.cat(vis, dim=1), torch.cat(msk, dim=1), pixels_cls_scores
 
+    # ---- multi-GPU evaluation: the gallery is sharded, nothing else is exchanged
+    def _world(self):
+        import torch.distributed as dist
+        if not (self.distributed and dist.is_initialized()):
+            return 1, 0
+        return dist.get_world_size(self.process_group), dist.get_rank(self.process_group)
+
     @torch.no_grad()
-    def feature_extraction(self, batches):
-        """batches: iterable of dicts with 'image' (+ optional 'mask', 'pid', 'camid')."""
+    def feature_extraction(self, batches, shard=False, gather=False):
+        """batches: iterable of dicts with 'image' (+ optional 'mask', 'pid', 'camid') -> (features [M,P,D], visibility [M,P] or
+        None, pids, camids), all in batch order (part_based_engine.py:132-166 without the per-batch .cpu()).
+
+        `shard=True` on a distributed engine: this rank runs the model on its contiguous share `gallery_shard(len(batches), world,
+        rank)` of the batches only (the gallery of BASELINE configs[4]: 20 000 images over 8 GPUs) and returns ITS rows -- the
+        form `evaluate(..., gallery_sharded=True)` takes.  `gather=True` additionally all-gathers the rows so that every rank
+        returns the full set in the original order (the queries, which every rank needs)."""
+        from .distributed import gallery_shard, all_gather_cat
         self.model.eval()
         dev = next(self.model.parameters()).device
+        world, rank = self._world()
+        if shard and world > 1:
+            batches = list(batches)
+            b0, b1 = gallery_shard(len(batches), world, rank)
+            batches = batches[b0:b1]
         feats, viss, pids, camids = [], [], [], []
         for data in batches:
             imgs = data['image'].to(dev)
@@ -201,23 +233,52 @@ class ImagePartBasedEngine:
             f, v, _, _ = self.extract_test_embeddings(self.model(imgs, external_parts_masks=masks))
             feats.append(f.clone())
             viss.append(v.clone())
-            pids.extend(list(data.get('pid', [])))
-            camids.extend(list(data.get('camid', [])))
-        return torch.cat(feats), (torch.cat(viss) if self.mask_filtering_testing else None), pids, camids
+            pids.extend(int(x) for x in data.get('pid', []))
+            camids.extend(int(x) for x in data.get('camid', []))
+        f = torch.cat(feats) if feats else torch.empty(0, device=dev)
+        v = (torch.cat(viss) if viss else torch.empty(0, device=dev)) if self.mask_filtering_testing else None
+        if shard and gather and world > 1:
+            f = all_gather_cat(f, 0, self.process_group)
+            v = all_gather_cat(v.to(torch.float32), 0, self.process_group).to(v.dtype) if v is not None else None
+            pids, camids = self._gather_labels(pids, dev), self._gather_labels(camids, dev)
+        return f, v, pids, camids
+
+    def _gather_labels(self, labels, dev):
+        from .distributed import all_gather_cat
+        return all_gather_cat(torch.as_tensor(list(labels), dtype=torch.int64, device=dev), 0, self.process_group).tolist()
 
     @torch.no_grad()
     def evaluate(self, qf, gf, q_vis, g_vis, q_pids, g_pids, q_camids, g_camids, dist_metric='euclidean',
-                 normalize_feature=True, max_rank=50, rerank=False):
+                 normalize_feature=True, max_rank=50, rerank=False, return_body_parts_distmat=False, gallery_sharded=False):
+        """-> (cmc, mAP, distmat [Q,G] on the host, body_parts_distmat [P,Q,G] on the host or None)  (part_based_engine.py:168-240).
+
+        Distance, (re-ranking) and CMC / mAP run on the GPU; the Q x G matrix goes to the host only as the returned value.  The
+        per-part matrix (1.47 GB at Q = 2048, G = 20 000, P = 9: the reference only reads it for its plots and the visual
+        ranking) is produced and copied on request only (`return_body_parts_distmat=True`).
+        `gallery_sharded=True` on a distributed engine: `gf`, `g_vis`, `g_pids`, `g_camids` are THIS rank's rows
+        (`feature_extraction(..., shard=True)`); every rank computes its [Q, G_r] block, the fill value is agreed with one scalar
+        all-reduce, the blocks and the labels are all-gathered along the gallery axis and every rank ranks the full matrix
+        (identical results on all ranks; with `return_body_parts_distmat` the returned per-part block is the local [P,Q,G_r])."""
+        from .distributed import sharded_part_distance, all_gather_cat
+        world, _ = self._world()
+        sharded = gallery_sharded and world > 1
         if normalize_feature:
             qf, gf = _l2_normalize(qf), _l2_normalize(gf)                            # engine.py:558 (F.normalize(p=2, dim=-1))
-        bp = lambda a, b, va, vb, dev=False: compute_distance_matrix_using_bp_features(
-            a, b, va, vb, self.dist_combine_strat, self.batch_size_pairwise_dist_matrix, True, dist_metric, return_device_tensors=dev)
-        # distance, (re-ranking) and CMC / mAP all on the GPU: the Q x G matrix goes to the host only as the returned value
-        d_qg, parts_dev = bp(qf, gf, q_vis, g_vis, True)
-        distmat, body_parts_distmat = d_qg.cpu(), parts_dev.cpu()
+        bp = lambda a, b, va, vb, parts=False: compute_distance_matrix_using_bp_features(
+            a, b, va, vb, self.dist_combine_strat, self.batch_size_pairwise_dist_matrix, True, dist_metric, return_device_tensors=True,
+            want_parts=parts)
+        if sharded:
+            local = lambda a, b, va, vb, strat, metric: part_distance_raw(a, b, va, vb, strat, metric, want_parts=return_body_parts_distmat)
+            d_qg, parts_dev = sharded_part_distance(qf, gf, q_vis, g_vis, self.dist_combine_strat, dist_metric, self.process_group, local)
+            g_pids, g_camids = self._gather_labels(g_pids, d_qg.device), self._gather_labels(g_camids, d_qg.device)
+            if rerank:           # the k-reciprocal neighbourhoods need the whole gallery on every rank (g-g matrix): gather the rows
+                gf = all_gather_cat(gf, 0, self.process_group)
+                g_vis = all_gather_cat(g_vis.to(torch.float32), 0, self.process_group).to(g_vis.dtype) if g_vis is not None else None
+        else:
+            d_qg, parts_dev = bp(qf, gf, q_vis, g_vis, return_body_parts_distmat)
+        body_parts_distmat = parts_dev.cpu() if (return_body_parts_distmat and parts_dev is not None) else None
         ranked_dev = d_qg
         if rerank:                                                   # part_based_engine.py:218-226, utils/rerank.py:30
-            ranked_dev = re_ranking(d_qg, bp(qf, qf, q_vis, q_vis, True)[0], bp(gf, gf, g_vis, g_vis, True)[0])
-            ranked = ranked_dev.cpu().numpy()
+            ranked_dev = re_ranking(d_qg, bp(qf, qf, q_vis, q_vis)[0], bp(gf, gf, g_vis, g_vis)[0])
         res = evaluate_rank(ranked_dev, q_pids, g_pids, q_camids, g_camids, max_rank=max_rank)
-        return res['cmc'], res['mAP'], (torch.from_numpy(ranked) if rerank else distmat), body_parts_distmat
+        return res['cmc'], res['mAP'], ranked_dev.cpu(), body_parts_distmat

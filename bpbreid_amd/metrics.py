@@ -29,12 +29,13 @@ def _check_args(dist_combine_strat, metric):
 
 
 def part_distance_raw(qf, gf, qf_parts_visibility=None, gf_parts_visibility=None, dist_combine_strat='mean',
-                      metric='euclidean', device=None, finalize=False):
+                      metric='euclidean', device=None, finalize=False, want_parts=True):
     """One launch of the distance kernel over (all queries) x (this gallery shard).  Returns device tensors
     (dist [Q,G], parts [P,Q,G], vmax [1] fp32): with `finalize=False` pairs without a shared visible part are still marked
     -1 and `vmax` holds the largest valid per-part distance of THIS shard -- a caller that shards the gallery reduces
     `vmax` (max) over the shards and then calls `fill_invalid` (distance.py:171-176, :214-216 take the max over the whole
-    gallery)."""
+    gallery).  `want_parts=False`: the [P,Q,G] per-part matrix is neither allocated nor written (`parts` is None) -- the
+    q-q / g-g calls of the re-ranking and callers that only rank (9.6 GB at G = 20 000, P = 6 for the g-g matrix)."""
     _check_args(dist_combine_strat, metric)
     dev = device or (qf.device if qf.device.type == 'cuda' else torch.device('cuda', torch.cuda.current_device()))
     nv.init_device()
@@ -46,13 +47,13 @@ def part_distance_raw(qf, gf, qf_parts_visibility=None, gf_parts_visibility=None
     qv = qf_parts_visibility.to(dev, torch.float32).contiguous() if mode else None
     gv = gf_parts_visibility.to(dev, torch.float32).contiguous() if mode else None
     strat = 1 if (dist_combine_strat == 'max' and mode != 2) else 0      # continuous visibility: mean only (distance.py:200)
-    parts = torch.empty(p, q, g, device=dev, dtype=torch.float32)
+    parts = torch.empty(p, q, g, device=dev, dtype=torch.float32) if want_parts else None
     dist = torch.empty(q, g, device=dev, dtype=torch.float32)
     qsq = torch.empty(q * p, device=dev, dtype=torch.float32)
     gsq = torch.empty(g * p, device=dev, dtype=torch.float32)
     mx = torch.zeros(1, device=dev, dtype=torch.int32)
     nv.call('bpb_part_distance', qd.data_ptr(), gd.data_ptr(), nv.ptr(qv), nv.ptr(gv), q, g, p, d, mode, strat,
-            1 if metric == 'cosine' else 0, qsq.data_ptr(), gsq.data_ptr(), mx.data_ptr(), parts.data_ptr(), dist.data_ptr(),
+            1 if metric == 'cosine' else 0, qsq.data_ptr(), gsq.data_ptr(), mx.data_ptr(), nv.ptr(parts), dist.data_ptr(),
             1 if finalize else 0, nv.stream())
     return dist, parts, mx.view(torch.float32), mode
 
@@ -65,14 +66,15 @@ def fill_invalid(x, vmax):
 
 def compute_distance_matrix_using_bp_features(qf, gf, qf_parts_visibility=None, gf_parts_visibility=None,
                                               dist_combine_strat='mean', batch_size_pairwise_dist_matrix=5000, use_gpu=True,
-                                              metric='euclidean', device=None, return_device_tensors=False):
+                                              metric='euclidean', device=None, return_device_tensors=False, want_parts=True):
     """`batch_size_pairwise_dist_matrix` is accepted for signature compatibility; 288 GB of HBM holds the whole
-    [P,Q,G] result so the gallery is not chunked (results are identical: the reference's chunking only bounds memory)."""
+    [P,Q,G] result so the gallery is not chunked (results are identical: the reference's chunking only bounds memory).
+    `want_parts=False` (extension): the per-part matrix is not produced and None is returned in its place."""
     dist, parts, _, _ = part_distance_raw(qf, gf, qf_parts_visibility, gf_parts_visibility, dist_combine_strat, metric, device,
-                                          finalize=True)
+                                          finalize=True, want_parts=want_parts)
     if return_device_tensors:
         return dist, parts
-    return dist.cpu(), parts.cpu()
+    return dist.cpu(), (parts.cpu() if parts is not None else None)
 
 
 def evaluate_rank(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50, eval_metric='default', q_anns=None, g_anns=None,
@@ -119,6 +121,8 @@ def _evaluate_rank_gpu(distmat, q_pids, g_pids, q_camids, g_camids, max_rank):
     matching gallery entries than the kernel's LDS table holds (2048): the host routine then serves the call."""
     dm = distmat.to(torch.float32).contiguous()
     nq, ng = dm.shape
+    if -(-ng // 64) * 8 > 32 * 1024:         # the kernel's LDS bit table holds 262 144 gallery entries: host routine beyond that
+        return None
     dev = dm.device
     ids = [torch.as_tensor(np.asarray(a), dtype=torch.int64).to(dev) for a in (q_pids, g_pids, q_camids, g_camids)]
     max_rank = min(max_rank, ng)

@@ -197,8 +197,12 @@ class BPBreID(nn.Module):
         if m.dim_reduce not in ('none', 'before_pooling', 'after_pooling', 'before_and_after_pooling'):
             raise NotImplementedError("dim_reduce=%r: 'after_pooling_with_dropout' crashes in the reference (nn.opout, "
                                       'bpbreid.py:337)' % (m.dim_reduce,))
-        if m.pooling != 'gwap' or m.normalization != 'identity':
-            raise NotImplementedError("accelerated path: pooling='gwap', normalization='identity'")
+        if m.pooling not in ('gwap', 'gap') or m.normalization != 'identity':
+            # 'gmp' (GlobalMaxPoolingHead, bpbreid.py:481-482: max over pixels of mask * feature) and the BatchNorm
+            # normalisations of the materialised [N*K, C, H, W] product are not offered
+            raise NotImplementedError("accelerated path: pooling in ('gwap', 'gap'), normalization='identity'; got %r / %r"
+                                      % (m.pooling, m.normalization))
+        self.parts_gap = m.pooling == 'gap'
         if m.test_use_target_segmentation not in ('none', 'soft', 'hard'):
             raise ValueError('test_use_target_segmentation must be none, soft or hard')
         if pretrained:
@@ -529,7 +533,7 @@ class _ModelPlan:
                 n, HW, K1, 1 if binary else 0, None if binary else self.argpix.data_ptr(), s())
         nv.call('bpb_masked_pool', x.data_ptr(), self.pm.data_ptr(), self.pool_part.data_ptr(), n, HW, Cc, J, None, s())
         nv.call('bpb_pool_finalize', self.pool_part.data_ptr(), self.pm.data_ptr(), self.pooled.data_ptr(),
-                self.zinv.data_ptr(), n, self.nchunks, J, HW, Cc, s())
+                self.zinv.data_ptr(), n, self.nchunks, J, HW, Cc, 1 if m.parts_gap else 0, s())
         # ---- after-pooling dim reduce (Linear + BN1d + ReLU); pooled rows: 0 global, 1 fg, 2 bg, 3.. parts
         o = {}
         f = lambda *sh: _f32(*sh, device=dev)

@@ -223,7 +223,7 @@ PROTOS = {
     'bpb_bilinear_concat_fwd': 'pp', 'bpb_bilinear_concat_bwd': 'ppp', 'bpb_bilinear_concat_multi_fwd': 'ppipipp',
     'bpb_bilinear_concat_multi_bwd': 'ppip',
     'bpb_pixel_dots': 'pplppiiiip', 'bpb_masked_pool': 'pppiiiipp', 'bpb_fold_bn': 'ppppppiip',
-    'bpb_softmax_masks': 'ppppppiiip', 'bpb_visibility': 'ppppiiiipp', 'bpb_pool_finalize': 'ppppiiiiip',
+    'bpb_softmax_masks': 'ppppppiiip', 'bpb_visibility': 'ppppiiiipp', 'bpb_pool_finalize': 'ppppiiiiiip',
     'bpb_rowdot': 'pppiip', 'bpb_resize_masks': 'ppiiiiiip', 'bpb_attention_from_masks': 'pppppiiiiip', 'bpb_head_bwd_dlogits': 'pppppppppiiipppp',
     'bpb_head_bwd_params': 'pipiiiiipppppppppppip', 'bpb_head_bwd_dx': 'ppppppppppppiiiiip',
     'bpb_gemm': 'pllpllplpiiiippp', 'bpb_gemm_grouped': 'piplpp', 'bpb_colsum': 'ppiiip',

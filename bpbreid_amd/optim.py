@@ -110,6 +110,15 @@ class FusedAdam:
             self.exp_avg_sq.copy_(sd['exp_avg_sq'])
             self.param_groups[0]['lr'] = sd['lr']
             self.step_dev.fill_(self.step_index)
+            # the flat format carries no per-parameter history: every parameter whose second moment is non-zero has been
+            # updated (state_dict() filters on `updated`; without this a resume + save would drop the Adam moments)
+            self.updated = set()
+            if self.step_index > 0:
+                nz = (self.exp_avg_sq != 0).cpu()      # (checkpoint load, not the step: one device read)
+                for i, (off, n) in enumerate(self.model._param_slices):
+                    if n and bool(nz[off:off + n].any()):
+                        self.updated.add(i)
+            self._last_key = None
             return
         own = {name: k for k, (name, _) in enumerate(self.model.named_parameters())}
         names = param_names if param_names is not None else list(own)

@@ -418,8 +418,10 @@ int bpb_attention_from_masks(const float* ext_r, float* probs, float* pm, unsign
  * foreground score -- where the backward of amax (bpbreid.py:186-189) puts the gradient of the visibility scores */
 int bpb_visibility(const float* probs, const unsigned char* argcls, float* vis, float* fgvis, int N, int HW, int K1,
                    int binary, int* argpix, hipStream_t stream);
+/* parts_gap != 0: the part rows (j >= 3) are normalised by 1/HW like the fg / bg rows -- pooling = 'gap'
+ * (GlobalAveragePoolingHead, bpbreid.py:432-441, :485-486) instead of 'gwap' (bpbreid.py:490-503) */
 int bpb_pool_finalize(const float* part, const float* pm, float* pooled, float* zinv, int N, int nchunks, int J, int HW,
-                      int C, hipStream_t stream);
+                      int C, int parts_gap, hipStream_t stream);
 int bpb_rowdot(const float* a, const float* b, float* out, int rows, int C, hipStream_t stream);
 int bpb_head_bwd_dlogits(const float* D, const float* probs, const unsigned char* argpart, const float* zinv,
                          const float* gp, const float* dlogit_ext, float* dlogit, double* lpart, int* nblocks_out, int N,

@@ -73,12 +73,15 @@ class _BNNeck(nn.Module):
 
 
 def _masked_pool(feats, masks, weighted):
-    """bpbreid.py:458-468 (GAP over m*x) and :490-503 (GWAP: sum(m*x)/clamp(sum m, 1e-6))."""
+    """bpbreid.py:458-468 + :485-486 (GAP over m*x), :481-482 (GMP: max over pixels of m*x) and :490-503 (GWAP:
+    sum(m*x)/clamp(sum m, 1e-6)).  `weighted`: True / 'gwap', False / 'gap', 'gmp'."""
     prod = masks.unsqueeze(2) * feats.unsqueeze(1)              # [N,M,C,H,W] materialised, as the reference
-    if weighted:
+    if weighted is True or weighted == 'gwap':
         s = prod.sum(dim=(-2, -1))
         z = masks.sum(dim=(-2, -1)).clamp(min=1e-6).unsqueeze(-1)
         return s / z
+    if weighted == 'gmp':
+        return prod.amax(dim=(-2, -1))
     return prod.mean(dim=(-2, -1))
 
 
@@ -93,7 +96,7 @@ class BPBreID(nn.Module):
             enable_dim_reduction=(m.dim_reduce == 'before_pooling'),
             dim_reduction_channels=m.dim_reduce_output)
         c = self.backbone_appearance_feature_extractor.feature_dim
-        assert m.pooling == 'gwap' and m.normalization == 'identity'
+        assert m.pooling in ('gwap', 'gap', 'gmp') and m.normalization == 'identity'      # bpbreid.py:432-441
         d = m.dim_reduce_output
         # init_dim_reduce_layers, bpbreid.py:84-114
         self.after_pooling = m.dim_reduce in ('after_pooling', 'before_and_after_pooling')
@@ -161,7 +164,7 @@ class BPBreID(nn.Module):
         g = feats.mean(dim=(2, 3))                                # AdaptiveAvgPool2d(1), :195
         f = _masked_pool(feats, fg.unsqueeze(1).to(feats.dtype), False).flatten(1, 2)
         b = _masked_pool(feats, bg.unsqueeze(1).to(feats.dtype), False).flatten(1, 2)
-        p = _masked_pool(feats, parts, True)
+        p = _masked_pool(feats, parts, m.pooling)
         if self.after_pooling:                                    # bpbreid.py:205-209
             g = self.global_after_pooling_dim_reduce(g)
             f = self.foreground_after_pooling_dim_reduce(f)

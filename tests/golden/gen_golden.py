@@ -117,6 +117,18 @@ MODEL_CASES = {
     'hrw8_k5_before': ('hrnet_w8', 5, 64, 8, 64, 32, 16, {'dim_reduce': 'before_pooling'}),
     'r50_k2_before': ('resnet50', 2, 64, 8, 128, 64, 16, {'dim_reduce': 'before_pooling'}),
     'r50_k2_before_after': ('resnet50', 2, 64, 8, 128, 64, 16, {'dim_reduce': 'before_and_after_pooling'}),
+    # round 3: every configuration branch once more on a 128x64 / batch-16 fixture (HRNet widths 16..128: the deepest branch
+    # is 4x2 pixels, BatchNorm populations >= 128 values) so that the branch itself is pinned at the TIGHT tolerance, plus the
+    # 'gap' / 'gmp' part pooling heads (bpbreid.py:432-441, :481-486)
+    'hrw16_k5_float_vis': ('hrnet_w16', 5, 128, 16, 128, 64, 16,
+                           {'training_binary_visibility_score': False, 'testing_binary_visibility_score': False}),
+    'hrw16_k3_shared': ('hrnet_w16', 3, 128, 16, 128, 64, 16, {'shared_parts_id_classifier': True}),
+    'hrw16_k5_soft': ('hrnet_w16', 5, 128, 16, 128, 64, 16, {'test_use_target_segmentation': 'soft'}),
+    'hrw16_k5_hard': ('hrnet_w16', 5, 128, 16, 128, 64, 16, {'test_use_target_segmentation': 'hard'}),
+    'hrw16_k5_nolearn': ('hrnet_w16', 5, 128, 16, 128, 64, 16, {'learnable_attention_enabled': False}),
+    'hrw16_k5_before': ('hrnet_w16', 5, 128, 16, 128, 64, 16, {'dim_reduce': 'before_pooling'}),
+    'hrw16_k5_gap': ('hrnet_w16', 5, 128, 16, 128, 64, 16, {'pooling': 'gap'}),
+    'hrw16_k5_gmp': ('hrnet_w16', 5, 128, 16, 128, 64, 16, {'pooling': 'gmp'}),
 }
 
 
@@ -411,6 +423,7 @@ if __name__ == '__main__':
     L.load_reference()
     register_hrnet_width('hrnet48', (48, 96, 192, 384))
     register_hrnet_width('hrnet_w8', (8, 16, 32, 64))
+    register_hrnet_width('hrnet_w16', (16, 32, 64, 128))
     what = sys.argv[1:] or ['loss', 'metric', 'model', 'traj']
     if 'loss' in what:
         gen_loss()

@@ -24,7 +24,8 @@ DEV = torch.device('cuda', 0)
 # Gradient digests are only asserted element-wise on the well-conditioned fixtures.  On the tiny 64x32 / 128x64 inputs
 # one near-tie flip of the (non-differentiable) arg-max part under fp32 round-off moves 1/1024 of the data, and
 # BatchNorm populations of 4..32 elements amplify round-off: there the check is a cosine over all sampled elements.
-WELL_CONDITIONED = ('hr32_k5', 'hr32_k5_full', 'r50_k5_full', 'hr48_k8')
+WELL_CONDITIONED = ('hr32_k5', 'hr32_k5_full', 'r50_k5_full', 'hr48_k8', 'hrw16_k5_float_vis', 'hrw16_k3_shared', 'hrw16_k5_soft',
+                    'hrw16_k5_hard', 'hrw16_k5_nolearn', 'hrw16_k5_before', 'hrw16_k5_gap')
 MODEL_CASES = {
     'hrw8_k5': ('hrnet_w8', {}),
     'hrw8_k5_float_vis': ('hrnet_w8', {'training_binary_visibility_score': False, 'testing_binary_visibility_score': False}),
@@ -43,6 +44,14 @@ MODEL_CASES = {
     'hrw8_k5_before': ('hrnet_w8', {'dim_reduce': 'before_pooling'}),
     'r50_k2_before': ('resnet50', {'dim_reduce': 'before_pooling'}),
     'r50_k2_before_after': ('resnet50', {'dim_reduce': 'before_and_after_pooling'}),
+    # round 3: the configuration branches on 128x64 / batch-16 fixtures (TIGHT tier) and the gap / gmp part pooling heads
+    'hrw16_k5_float_vis': ('hrnet_w16', {'training_binary_visibility_score': False, 'testing_binary_visibility_score': False}),
+    'hrw16_k3_shared': ('hrnet_w16', {'shared_parts_id_classifier': True}),
+    'hrw16_k5_soft': ('hrnet_w16', {'test_use_target_segmentation': 'soft'}),
+    'hrw16_k5_hard': ('hrnet_w16', {'test_use_target_segmentation': 'hard'}),
+    'hrw16_k5_nolearn': ('hrnet_w16', {'learnable_attention_enabled': False}),
+    'hrw16_k5_before': ('hrnet_w16', {'dim_reduce': 'before_pooling'}),
+    'hrw16_k5_gap': ('hrnet_w16', {'pooling': 'gap'}),
 }
 WEIGHTS_MARKET = {'globl': {'id': 1., 'tr': 0.}, 'foreg': {'id': 1., 'tr': 1.}, 'conct': {'id': 1., 'tr': 0.},
                   'parts': {'id': 0., 'tr': 1.}, 'pixls': {'ce': 0.35}}
@@ -55,7 +64,8 @@ WEIGHTS_DEFAULT = {'globl': {'id': 1., 'tr': 0.}, 'foreg': {'id': 1., 'tr': 0.},
 # BatchNorm over a handful of values amplifies round-off by 1/sigma and the bound is 3x wider.  The eval-only 'soft' / 'hard'
 # target-segmentation fixtures apply running statistics of train-mode embeddings to differently masked eval embeddings: dead
 # ReLU features (running variance ~0) amplify the difference by 1/sqrt(eps) = 316, same wider bound.
-TIGHT = ('hr32_k5', 'hr32_k5_full', 'r50_k2', 'r50_k5_full', 'hr48_k8', 'r50_k2_nolearn', 'r50_k2_before', 'r50_k2_before_after')
+TIGHT = ('hr32_k5', 'hr32_k5_full', 'r50_k2', 'r50_k5_full', 'hr48_k8', 'r50_k2_nolearn', 'r50_k2_before', 'r50_k2_before_after',
+         'hrw16_k5_float_vis', 'hrw16_k3_shared', 'hrw16_k5_soft', 'hrw16_k5_hard', 'hrw16_k5_nolearn', 'hrw16_k5_before', 'hrw16_k5_gap')
 
 
 def close(got, ref32, ref64, c=4.0, rel=1e-4, what=''):
@@ -177,36 +187,45 @@ def test_model_matches_reference_golden(name, golden_dir):
         if err > max(20 * noise, 1e-2 * scale):
             bad.append((pn, err, noise, scale))
     cosine = dots[0] / np.sqrt(dots[1] * dots[2])
-    float_vis = extra.get('training_binary_visibility_score', True) is False
-    if float_vis:
-        # continuous visibility scores are differentiable (amax over pixels feeds the CE weights and the triplet pair mask,
-        # bpbreid.py:186-189): same bound as the other 64x32 fixtures (0.93 when they were treated as constants)
-        assert cosine > 0.98, cosine
-    elif name in WELL_CONDITIONED:
-        rr = np.array(ratios)
-        rms_err, rms_noise = np.sqrt((rr[:, 0] ** 2).mean()), np.sqrt((rr[:, 1] ** 2).mean())
-        os.makedirs('gpurun_out', exist_ok=True)
-        with open('gpurun_out/grad_parity_%s.txt' % name, 'w') as fh:
-            fh.write('# %d parameters, %d outside max(4*noise, 1e-3*scale), %d outside max(20*noise, 1e-2*scale); rms err/scale '
-                     '%.3e vs reference fp32 noise/scale %.3e (x%.2f); median err/noise x%.2f; cosine %.7f\n'
-                     % (len(digests), len(loose), len(bad), rms_err, rms_noise, rms_err / rms_noise,
-                        np.median(rr[:, 0] / np.maximum(rr[:, 1], 1e-30)), cosine))
-            for b in loose:
-                fh.write('%s err=%.3e noise=%.3e scale=%.3e\n' % b)
+    # the reference's own fp32 run against its fp64 run, same normalisation: the yardstick for the direction test
+    rdots = np.zeros(3)
+    for pn in digests:
+        r32, r64 = z['f32/grad/' + pn], z['f64/grad/' + pn]
+        scale = max(np.abs(r64[2:]).max(), np.abs(r64[1]) / max(1, r64.size), 1e-9)
+        if scale > 1e-7:
+            rdots += [np.dot(r32[2:], r64[2:]) / scale ** 2, np.dot(r32[2:], r32[2:]) / scale ** 2, np.dot(r64[2:], r64[2:]) / scale ** 2]
+    cosine_ref = rdots[0] / np.sqrt(rdots[1] * rdots[2])
+    rr = np.array(ratios)
+    rms_err, rms_noise = np.sqrt((rr[:, 0] ** 2).mean()), np.sqrt((rr[:, 1] ** 2).mean())
+    os.makedirs('gpurun_out', exist_ok=True)
+    with open('gpurun_out/grad_parity_%s.txt' % name, 'w') as fh:
+        fh.write('# %d parameters, %d outside max(4*noise, 1e-3*scale), %d outside max(20*noise, 1e-2*scale); rms err/scale '
+                 '%.3e vs reference fp32 noise/scale %.3e (x%.2f); median err/noise x%.2f; cosine %.7f (reference fp32 vs fp64: %.7f)\n'
+                 % (len(digests), len(loose), len(bad), rms_err, rms_noise, rms_err / max(rms_noise, 1e-30),
+                    np.median(rr[:, 0] / np.maximum(rr[:, 1], 1e-30)), cosine, cosine_ref))
+        for b in loose:
+            fh.write('%s err=%.3e noise=%.3e scale=%.3e\n' % b)
+    if name in WELL_CONDITIONED:
         # Gradients sit behind ~10^7 ReLU decisions: an activation within round-off of zero flips under ANY change of summation
         # order and moves a per-channel gradient sum by one element's worth (1/128 of it on a 4x2 map at batch 16).  The
         # reference itself, fp32, with channels_last convolutions (tests/golden/noise_control.py, noise_control_r02.txt) leaves
         # 0.7-1.6 % of the parameters outside the per-parameter contract bound max(4*noise, 1e-3*scale) and none outside
-        # max(20*noise, 1e-2*scale).  Asserted here:
-        #   (1) in aggregate the GPU is as accurate as the reference's own fp32 run: rms(err/scale) <= 2 x rms(noise/scale);
-        #   (2) >= 92 % of the parameters inside the per-parameter contract bound, >= 99 % inside the wide bound;
-        #   (3) direction: cosine over all sampled gradient elements > 0.9995.
-        assert rms_err <= 2.0 * rms_noise + 1e-3, (rms_err, rms_noise)
-        assert len(loose) <= 0.08 * len(digests), (len(loose), len(digests), loose[:6])
-        assert len(bad) <= 0.01 * len(digests), (len(bad), len(digests), bad[:6])
-        assert cosine > 0.9995, cosine
+        # max(20*noise, 1e-2*scale).  Asserted here (round 3: tightened to what the build achieves -- 0-0.7 %, 0, 0.57-0.92x):
+        #   (1) in aggregate the GPU is as accurate as the reference's own fp32 run: rms(err/scale) <= 1.2 x rms(noise/scale);
+        #   (2) <= 2 % of the parameters outside the per-parameter contract bound, NONE outside the wide bound;
+        #   (3) direction: the cosine over all sampled gradient elements is > 0.9999, or -- where the reference's own fp32 run
+        #       is further than that from its fp64 run (ResNet-50 full size: 0.99988) -- within 1.5x of the reference's distance.
+        assert rms_err <= 1.2 * rms_noise + 1e-3, (rms_err, rms_noise)
+        assert len(loose) <= 0.02 * len(digests), (len(loose), len(digests), loose[:6])
+        assert len(bad) == 0, (len(bad), len(digests), bad[:6])
+        assert 1.0 - cosine <= max(1e-4, 1.5 * (1.0 - cosine_ref)), (cosine, cosine_ref)
     else:
+        # 64x32 fixtures (feature maps down to 2x1 pixels, BatchNorm populations of 8..32 values) and the small ResNet ones: one
+        # arg-max / ReLU flip moves 1/1024 of the data, so individual parameters are chaotic at fp32; bounded in aggregate
+        # (never by the cosine alone): direction, rms error relative to the gradient scale, and no parameter off by its scale
         assert cosine > 0.98, cosine
+        assert rms_err <= max(25.0 * rms_noise, 5e-2), (rms_err, rms_noise)
+        assert (rr[:, 0] > 1.0).mean() <= 0.02, float((rr[:, 0] > 1.0).mean())
     sd = model.state_dict()
     rs = [kk for kk in sd if kk.endswith('running_mean') or kk.endswith('running_var')]
     got = np.array([float(sd[kk].double().sum()) for kk in rs])

@@ -33,6 +33,15 @@ MODEL_CASES = {
     'hrw8_k5_before': ('hrnet_w8', {'dim_reduce': 'before_pooling'}),
     'r50_k2_before': ('resnet50', {'dim_reduce': 'before_pooling'}),
     'r50_k2_before_after': ('resnet50', {'dim_reduce': 'before_and_after_pooling'}),
+    # round 3: the configuration branches on 128x64 / batch-16 fixtures (TIGHT tier) and the gap / gmp part pooling heads
+    'hrw16_k5_float_vis': ('hrnet_w16', {'training_binary_visibility_score': False, 'testing_binary_visibility_score': False}),
+    'hrw16_k3_shared': ('hrnet_w16', {'shared_parts_id_classifier': True}),
+    'hrw16_k5_soft': ('hrnet_w16', {'test_use_target_segmentation': 'soft'}),
+    'hrw16_k5_hard': ('hrnet_w16', {'test_use_target_segmentation': 'hard'}),
+    'hrw16_k5_nolearn': ('hrnet_w16', {'learnable_attention_enabled': False}),
+    'hrw16_k5_before': ('hrnet_w16', {'dim_reduce': 'before_pooling'}),
+    'hrw16_k5_gap': ('hrnet_w16', {'pooling': 'gap'}),
+    'hrw16_k5_gmp': ('hrnet_w16', {'pooling': 'gmp'}),
 }
 WEIGHTS_MARKET = {'globl': {'id': 1., 'tr': 0.}, 'foreg': {'id': 1., 'tr': 1.},
                   'conct': {'id': 1., 'tr': 0.}, 'parts': {'id': 0., 'tr': 1.}}

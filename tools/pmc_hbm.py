@@ -58,6 +58,11 @@ for k in sorted(set(fetch) | set(write)):
     w_avg = sw / nw if nw else 0.0
     out[k] = {'launches': max(nf, nw), 'fetch_size_kb_per_launch': f_avg, 'write_size_kb_per_launch': w_avg,
               'hbm_bytes_per_launch': (2.0 * f_avg + w_avg) * 1024.0}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bpbreid_amd.build import source_id                       # noqa: E402
+out['_build'] = {'source_id': source_id(), 'note': 'sha256 prefix of csrc/ + include/bpbreid_hip.h of the build these counters '
+                                                   'were collected on; bench.py quotes `traffic` only when it matches its own build'}
 json.dump(out, open(sys.argv[3], 'w'), indent=1, sort_keys=True)
+del out['_build']
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches'])[:10]:
     print('%-60s n=%5d  %.2f MB/launch' % (k[:60], v['launches'], v['hbm_bytes_per_launch'] / 1e6))
