@@ -117,3 +117,37 @@ def test_gallery_shard_bounds():
         cuts = [gallery_shard(n, w, r) for r in range(w)]
         assert cuts[0][0] == 0 and cuts[-1][1] == n and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
         assert max(e - b for b, e in cuts) - min(e - b for b, e in cuts) <= 1
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from bpbreid_amd.distributed import all_gather_cat, gallery_shard
+    full = torch.arange(7 * 3 * 5, dtype=torch.float32).view(7, 3, 5)
+    b, e = gallery_shard(7, world, rank)                       # 4 + 3 rows
+    rows = all_gather_cat(full[b:e], 0)
+    cols = all_gather_cat(full.permute(1, 0, 2)[:, b:e], 1)   # ragged along a middle dimension, non-contiguous input
+    ids = all_gather_cat(torch.arange(b, e, dtype=torch.int64), 0)
+    empty = all_gather_cat(full[:0] if rank == 1 else full[:2], 0)      # a rank without rows
+    q.put((rank, rows.numpy().copy(), cols.numpy().copy(), ids.numpy().copy(), empty.numpy().copy(), cols.is_contiguous()))
+    dist.destroy_process_group()
+
+
+def test_all_gather_cat_ragged_world2():
+    """distributed.all_gather_cat (the exchange of the gallery-sharded evaluation: distance blocks along the gallery axis,
+    feature rows, labels): ragged shards, any dimension, a rank without rows; identical result on both ranks."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    full = torch.arange(7 * 3 * 5, dtype=torch.float32).view(7, 3, 5).numpy()
+    for _, rows, cols, ids, empty, contiguous in res:
+        assert (rows == full).all() and (cols == full.transpose(1, 0, 2)).all() and contiguous
+        assert ids.tolist() == list(range(7)) and (empty == full[:2]).all()

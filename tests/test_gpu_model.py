@@ -521,7 +521,13 @@ def test_engine_evaluate_end_to_end_on_device_matches_the_oracle(rerank):
     eng = ImagePartBasedEngine(model, optimizer=FusedAdam(model), losses_weights=WEIGHTS_MARKET)
     cmc, mAP, dist, parts = eng.evaluate(qf.to(DEV), gf.to(DEV), qv.to(DEV), gv.to(DEV), qid.numpy(), gid.numpy(), qc, gc,
                                          max_rank=20, rerank=rerank)
+    assert parts is None          # the [P,Q,G] per-part matrix is produced and copied to the host on request only
+    cmc2, mAP2, dist2, parts = eng.evaluate(qf.to(DEV), gf.to(DEV), qv.to(DEV), gv.to(DEV), qid.numpy(), gid.numpy(), qc, gc,
+                                            max_rank=20, rerank=rerank, return_body_parts_distmat=True)
+    assert np.array_equal(cmc, cmc2) and mAP == mAP2 and torch.equal(dist, dist2)       # same kernel, with and without the stores
     nrm = lambda t: torch.nn.functional.normalize(t, p=2, dim=-1)
+    ref_parts = OM.part_based_distance(nrm(qf), nrm(gf), qv, gv, 'mean', 5000, 'euclidean')[1]
+    assert tuple(parts.shape) == (p, nq, ng) and (parts - ref_parts).abs().max() < 5e-6
     bp = lambda a, b, va, vb: OM.part_based_distance(nrm(a), nrm(b), va, vb, 'mean', 5000, 'euclidean')[0]
     ref = bp(qf, gf, qv, gv).numpy()
     if rerank:
@@ -595,6 +601,37 @@ def test_two_rank_gradient_exchange_with_different_batches_matches_single_proces
     assert info['grad_abs_max'] > 0 and info['grad_elements'] > 1000
     assert info['bit_equal'], info
     assert info['buckets'] >= 4 and info['early_buckets'] >= info['buckets'] - 1, info
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rerank', [0, 1])
+def test_gallery_sharded_evaluation_through_the_engine_world2(rerank):
+    """tests/eval_shard_check.py: two ranks (sharing this GPU over gloo).  engine.feature_extraction(shard=True) runs each rank's
+    share of the query / gallery batches, engine.evaluate(gallery_sharded=True) computes [Q, G_r] blocks, agrees the fill value
+    with one scalar all-reduce, all-gathers blocks and labels and ranks the full matrix: distance matrix, CMC and mAP identical to
+    the single-process evaluation (part_based_engine.py:168-240)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for kk in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(kk, None)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    run = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                          '127.0.0.1', '--master-port', str(port), os.path.join(root, 'tests', 'eval_shard_check.py'), '--backend', 'gloo',
+                          '--rerank', str(rerank)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
+    assert run.returncode == 0, run.stderr.decode()[-3000:]
+    info = json.loads([l for l in run.stdout.decode().splitlines() if l.startswith('{')][-1])
+    assert info['world'] == 2 and info['ranks_agree'], info
+    assert info['q_rows'] == info['q_rows_single'] == 21 and info['g_rows_single'] == 37 and info['g_rows_local'] == 24, info
+    assert info['dm_shape'] == [21, 37] and info['features_equal'] and info['labels_equal'], info
+    assert info['dist_equal'] and info['cmc_equal'] and info['map_diff'] == 0.0, info
+    assert 0.0 < info['mAP'] <= 1.0
 
 
 @pytest.mark.gpu
