@@ -98,11 +98,11 @@ def sharded_part_distance(qf, gf_local, qf_parts_visibility=None, gf_local_parts
         if d.is_cuda:
             from .metrics import fill_invalid
             fill_invalid(d, vmax)
-            if mode == 1:
+            if mode == 1 and parts is not None:
                 fill_invalid(parts, vmax)
         else:
             d[d == -1] = vmax + 1
-            if mode == 1:
+            if mode == 1 and parts is not None:
                 parts[parts == -1] = vmax + 1
     if world == 1:
         return d, parts
