@@ -27,11 +27,27 @@ __device__ __forceinline__ unsigned s1_fdiv(unsigned x, unsigned d, unsigned mag
     return d == 1 ? x : __umulhi(x, magic);
 }
 
+#ifdef BPB_S1_TRACE
+// Measurement build only (tools/s1_trace.py links it into a separate library; never part of libbpbreid_hip.so): every wave
+// stamps s_memtime at its phase boundaries -- entry, prologue done, first chunk landed, MFMA loop done, exit -- plus where it ran.
+__device__ unsigned long long* g_s1_trace = nullptr;
+#define S1_TR(i) do { if (g_s1_trace && (threadIdx.x & 63) == 0) g_s1_trace[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define S1_TR(i) do { } while (0)
+#endif
+// Ablation switches of the measurement build (results are WRONG with any of them; they answer "what does a chunk's time consist
+// of"): 1 no DMA after the first chunk, 2 no barrier after the first chunk, 4 no LDS reads inside the MFMA loop, 8 no per-chunk
+// accumulator bookkeeping, 16 no address updates.
+#ifndef S1_ABL
+#define S1_ABL 0
+#endif
+
 template <int NT, int MT, int R, int KG>   // KG = 8-channel k-groups per tap and pipeline stage: channel chunk CK = 8 * KG
 __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob* __restrict__ probs, int nprobs)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int T = R * R, PAD = R / 2, CK = 8 * KG, NJ = T * KG;
+    S1_TR(0);
     int bid = blockIdx.x;
     int pi = 0;
     for (int i = 1; i < nprobs; ++i)
@@ -174,23 +190,33 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) apix[t][mt] = pixoff[mt] + ((t / R) * HWd + (t % R)) * LD * 4;
     const int bstride = 2 * NTC * 16;          // bytes of one k-group of the weight tile
+    S1_TR(1);
     dma_issue(0, 0);
     for (int c = 0; c < nch; ++c) {
-        __syncthreads();   // chunk c has landed (the barrier drains vmcnt) and the other buffer is free again
-        if (c + 1 < nch) dma_issue((c + 1) * CK, (c + 1) & 1);
+        if (!(S1_ABL & 2) || c == 0) __syncthreads();   // chunk c has landed (the barrier drains vmcnt) and the other buffer is free again
+        if (c == 0) S1_TR(2);
+        if (c + 1 < nch && (!(S1_ABL & 1) || c == 0)) dma_issue((c + 1) * CK, (c + 1) & 1);
         const char* lds = (const char*)smem;
         int bptr = (c & 1) * bufbytes + halo_reg * 16 + boff_lane;
         // Two-level summation: the MFMAs of one channel chunk (T * CK products per output) accumulate into `cacc`, the chunk sums
         // are added to `acc` at the end of the chunk.  A single fp32 chain over K = T * Cin (up to 2304) products grows its
         // round-off like sqrt(K); chunks of 72..288 products + Cin / CK chunk sums keep it at the level of the CPU reference's
         // blocked sums (tools/diag_noise.py) for 16 * MT * NT extra VALU adds per chunk.
-        f32x16 cacc[MT][NT];
+        // (NA = 2 interleaved accumulator sets for the single-tile wave -- consecutive MFMAs independent of each other -- measured
+        // no gain, tools/s1_trace.py round 3: S1_NA of the measurement build.)
+#ifndef S1_NA
+#define S1_NA 1
+#endif
+        constexpr int NA = (MT * NT == 1) ? S1_NA : 1;
+        f32x16 cacc[NA][MT][NT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int a = 0; a < NA; ++a)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) cacc[mt][nt][r] = 0.f;
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cacc[a][mt][nt][r] = 0.f;
         // ping-pong operand sets: the LDS reads of k-group j+1 are in flight while the 4*MT*NT MFMAs of k-group j run
         f32x4 fa[2][MT], fb[2][NT];
 #pragma unroll
@@ -199,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob
         for (int nt = 0; nt < NT; ++nt) fb[0][nt] = *(const f32x4*)(lds + bptr + nt * 512);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            if (j + 1 < NJ) {
+            if (j + 1 < NJ && !(S1_ABL & 4)) {
                 bptr += bstride;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) fa[(j + 1) & 1][mt] = *(const f32x4*)(lds + apix[(j + 1) / KG][mt] + ((j + 1) % KG) * 32);
@@ -212,7 +238,8 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) cacc[mt][nt] = MFMA32(fa[j & 1][mt][i], fb[j & 1][nt][i], cacc[mt][nt]);
+                    for (int nt = 0; nt < NT; ++nt)
+                        cacc[i & (NA - 1)][mt][nt] = MFMA32(fa[(S1_ABL & 4) ? 0 : (j & 1)][mt][i], fb[(S1_ABL & 4) ? 0 : (j & 1)][nt][i], cacc[i & (NA - 1)][mt][nt]);
             __builtin_amdgcn_sched_barrier(0);
         }
         // next chunk lives in the other buffer
@@ -220,15 +247,17 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) apix[t][mt] += delta;
+            for (int mt = 0; mt < MT; ++mt) if (!(S1_ABL & 16)) apix[t][mt] += delta;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][nt][r] += cacc[mt][nt][r];
+                for (int r = 0; r < 16; ++r)
+                    if (!(S1_ABL & 8) || c + 1 == nch) acc[mt][nt][r] += NA == 2 ? cacc[0][mt][nt][r] + cacc[NA - 1][mt][nt][r] : cacc[0][mt][nt][r];
     }
 
+    S1_TR(3);
     // ---- epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31 (channel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
     // Stores (and the loads of the accumulate mode) go through a buffer descriptor; an invalid pixel adds 2^31 and an invalid
     // channel 2^30 to the 32-bit offset, so every invalid combination is dropped by the hardware (y is <= 1 GiB, host check).
@@ -393,6 +422,16 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob
             }
         }
     }
+#ifdef BPB_S1_TRACE
+    __builtin_amdgcn_s_waitcnt(0);            // (vmcnt / lgkmcnt 0: the stores have been accepted)
+    S1_TR(4);
+    if (g_s1_trace && (threadIdx.x & 63) == 0) {
+        unsigned long long* t = g_s1_trace + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
+        t[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
+        t[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
+        t[7] = (unsigned long long)pi;
+    }
+#endif
 }
 
 // ------------------------------------ C ABI ------------------------------------------
@@ -406,6 +445,14 @@ static int conv_s1_lds_bytes(const BpbConvS1Prob& p)
 }
 
 extern "C" {
+
+#ifdef BPB_S1_TRACE
+int bpb_conv_s1_set_trace(unsigned long long* buf)
+{
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_s1_trace), &buf, sizeof(buf));
+    return e == hipSuccess ? 0 : bpb_set_error((int)e, "bpb_conv_s1_set_trace: %s", hipGetErrorString(e));
+}
+#endif
 
 int bpb_conv_s1_init(void)
 {
