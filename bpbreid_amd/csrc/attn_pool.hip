@@ -18,13 +18,16 @@
 // ---------------------------------------------------------------------------------------------
 template <int J>
 __global__ __launch_bounds__(256) void bpb_pixel_dots_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                             long w_image_stride, const float* __restrict__ bias,
+                                                             long w_image_stride, long w_row_stride, const float* __restrict__ bias,
                                                              float* __restrict__ out, int HW, int C, int pix_per_block)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // w rows [J][C]
     const int n = blockIdx.y;
     const float* wn = w + (long)n * w_image_stride;
-    for (int i = threadIdx.x; i < J * (C >> 2); i += 256) *(f32x4*)(smem + i * 4) = *(const f32x4*)(wn + i * 4);
+    for (int i = threadIdx.x; i < J * (C >> 2); i += 256) {
+        const int j = i / (C >> 2), q = i - j * (C >> 2);          // (rows may be a column block of a wider matrix)
+        *(f32x4*)(smem + i * 4) = *(const f32x4*)(wn + j * w_row_stride + q * 4);
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c4 = C >> 2;
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(256) void bpb_visibility_kernel(const float* __rest
 // the backward then drops the -S/Z^2 term.  Deterministic fixed-order sum.
 __global__ __launch_bounds__(256) void bpb_pool_finalize_kernel(const float* __restrict__ part, const float* __restrict__ pm,
                                                                 float* __restrict__ pooled, float* __restrict__ zinv,
-                                                                int nchunks, int J, int HW, int C, int parts_gap)
+                                                                int nchunks, int J, int HW, int C, int parts_gap, int c0, int Ct)
 {
     __shared__ float red[256];
     const int n = blockIdx.y, j = blockIdx.x;
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(256) void bpb_pool_finalize_kernel(const float* __r
     for (int c = threadIdx.x; c < C; c += 256) {
         float s = 0.f;
         for (int q = 0; q < nchunks; ++q) s += part[(((long)n * nchunks + q) * J + j) * C + c];
-        pooled[((long)n * J + j) * C + c] = s * norm;
+        pooled[((long)n * J + j) * Ct + c0 + c] = s * norm;      // (part holds the C channels [c0, c0 + C) of Ct pooled channels)
     }
 }
 
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(256) void bpb_rowdot_kernel(const float* __restrict
 //   dbeta = S1, dgamma = S2, dW[k][c] = gamma*A + beta*L, dbias = L ;  k1 = S1/M, k2 = S2/M
 __global__ __launch_bounds__(1024) void bpb_head_bwd_params_kernel(const float* __restrict__ part, int nparts,
                                                                    const double* __restrict__ lpart, int nlpart, long npix_total, int HW,
-                                                                   int K1, int C, const float* __restrict__ W,
+                                                                   int K1, int C, int ldw, const float* __restrict__ W,
                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                    float* __restrict__ dW, float* __restrict__ dbias,
@@ -560,11 +563,11 @@ __global__ __launch_bounds__(1024) void bpb_head_bwd_params_kernel(const float* 
         for (int k = 0; k < BPB_HEAD_MAXJ; ++k) {
             if (k < K1) {
                 const double a = (araw[k] - (double)mu * L[k]) * (double)is;
-                const double w = (double)W[(long)k * C + c];
+                const double w = (double)W[(long)k * ldw + c];
                 s1 += w * L[k];
                 s2 += w * a;
                 const float dw = (float)((double)g * a + (double)b * L[k]);
-                dW[(long)k * C + c] = accumulate ? dW[(long)k * C + c] + dw : dw;
+                dW[(long)k * ldw + c] = accumulate ? dW[(long)k * ldw + c] + dw : dw;
             }
         }
         dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
@@ -718,18 +721,18 @@ int bpb_head_init(void)
     return 0;
 }
 
-// out[n][p][j] = sum_c w[n*w_image_stride + j*C + c] x[n][p][c] + bias[j]
-int bpb_pixel_dots(const float* x, const float* w, long w_image_stride, const float* bias, float* out, int N, int HW, int C,
-                   int J, hipStream_t stream)
+// out[n][p][j] = sum_c w[n*w_image_stride + j*w_row_stride + c] x[n][p][c] + bias[j]
+int bpb_pixel_dots(const float* x, const float* w, long w_image_stride, long w_row_stride, const float* bias, float* out, int N,
+                   int HW, int C, int J, hipStream_t stream)
 {
-    BPB_REQUIRE(C % 4 == 0 && N >= 1 && HW >= 1, "bpb_pixel_dots: bad sizes");
+    BPB_REQUIRE(C % 4 == 0 && N >= 1 && HW >= 1 && w_row_stride % 4 == 0 && ((uintptr_t)w & 15) == 0, "bpb_pixel_dots: bad sizes");
     BPB_REQUIRE((long)J * C * 4 <= 150 * 1024, "bpb_pixel_dots: weight rows do not fit in LDS");
     int ppb = 64;
     while (ppb > 16 && (long)N * bpb_cdiv(HW, ppb) < 1024) ppb >>= 1;
     const dim3 grid(bpb_cdiv(HW, ppb), N);
     const int lds = J * C * 4;
 #define BPB_PD(JJ) \
-    hipLaunchKernelGGL(bpb_pixel_dots_kernel<JJ>, grid, dim3(256), lds, stream, x, w, w_image_stride, bias, out, HW, C, ppb)
+    hipLaunchKernelGGL(bpb_pixel_dots_kernel<JJ>, grid, dim3(256), lds, stream, x, w, w_image_stride, w_row_stride, bias, out, HW, C, ppb)
     BPB_DISPATCH_J(J, BPB_PD)
 #undef BPB_PD
     BPB_LAUNCH_OK();
@@ -808,10 +811,11 @@ int bpb_visibility(const float* probs, const unsigned char* argcls, float* vis, 
 }
 
 int bpb_pool_finalize(const float* part, const float* pm, float* pooled, float* zinv, int N, int nchunks, int J, int HW,
-                      int C, int parts_gap, hipStream_t stream)
+                      int C, int parts_gap, int c0, int Ct, hipStream_t stream)
 {
+    BPB_REQUIRE(c0 >= 0 && c0 + C <= Ct, "bpb_pool_finalize: channel block [%d, %d) of %d", c0, c0 + C, Ct);
     hipLaunchKernelGGL(bpb_pool_finalize_kernel, dim3(J, N), dim3(256), 0, stream, part, pm, pooled, zinv, nchunks, J, HW, C,
-                       parts_gap);
+                       parts_gap, c0, Ct);
     BPB_LAUNCH_OK();
     return 0;
 }
@@ -838,12 +842,13 @@ int bpb_head_bwd_dlogits(const float* D, const float* probs, const unsigned char
     return 0;
 }
 
-int bpb_head_bwd_params(const float* part, int nparts, const double* lpart, int nlpart, int N, int HW, int K1, int C, const float* W,
-                        const float* gamma, const float* beta, const float* mean, const float* invstd, float* dW,
+int bpb_head_bwd_params(const float* part, int nparts, const double* lpart, int nlpart, int N, int HW, int K1, int C, int ldw,
+                        const float* W, const float* gamma, const float* beta, const float* mean, const float* invstd, float* dW,
                         float* dbias, float* dgamma, float* dbeta, float* k1, float* k2, int accumulate, hipStream_t stream)
 {
+    BPB_REQUIRE(ldw >= C, "bpb_head_bwd_params: ldw=%d < C=%d", ldw, C);
     hipLaunchKernelGGL(bpb_head_bwd_params_kernel, dim3(bpb_cdiv(C, 32)), dim3(1024), 0, stream, part, nparts, lpart, nlpart,
-                       (long)N * HW, HW, K1, C, W, gamma, beta, mean, invstd, dW, dbias, dgamma, dbeta, k1, k2, accumulate);
+                       (long)N * HW, HW, K1, C, ldw, W, gamma, beta, mean, invstd, dW, dbias, dgamma, dbeta, k1, k2, accumulate);
     BPB_LAUNCH_OK();
     return 0;
 }

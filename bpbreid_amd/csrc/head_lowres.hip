@@ -1,0 +1,438 @@
+// The part-attention head of an HRNet backbone WITHOUT the concatenated feature map.
+//
+// The reference up-samples the four branch outputs bilinearly (align_corners) to the first branch's resolution and concatenates
+// them into one map M = [U_0 x_0 | U_1 x_1 | U_2 x_2 | U_3 x_3] (torchreid/models/hrnet.py:568-573: 64 x 64x32 pixels x 1920
+// channels = 1.007 GB at batch 64), then runs the pixel classifier (BatchNorm2d + 1x1 convolution, bpbreid.py:376-385), the
+// soft-max attention and the mask-weighted poolings (bpbreid.py:195-202, 458-503) over it.  Every one of those operations is
+// LINEAR in M along the pixel axis, and bilinear up-sampling U_b is a fixed linear map per channel, so they commute:
+//     logits      W M + b          = sum_b U_b (W_b x_b) + b                    (6 channels up-sampled instead of 1920)
+//     pooling     sum_p a[p] M[p]  = sum_q (U_b^T a)[q] x_b[q]                  (the masks are DOWN-sampled by the adjoint)
+//     BatchNorm   sum_p M[p]       = sum_q (U_b^T 1)[q] x_b[q]
+//                 sum_p M[p]^2     = sum_q x_b[q] (U_b^T U_b x_b)[q]            (U^T U = G_h (x) G_w, both tridiagonal: 9 taps)
+//     backward    dx_b = U_b^T dM, with dM a sum of (pixel coefficient) x (channel vector) terms: the same adjoint.
+// The branch outputs are 126 MB where the map is 1 GB: the nine passes over the map of a training step (write, logits, pooling,
+// two backward reductions, dM read + write, the up-sampling backward) become passes over the branch outputs.  Results differ
+// from the materialised form by summation order only.  The map itself is still produced on request (spatial_features output).
+//
+// Kernels here: BatchNorm statistics of the virtual map, up-sampling sum of the per-branch logits, adjoint (transposed)
+// resampling of per-pixel coefficients, and the data gradient into the branch outputs.  The per-branch channel reductions
+// reuse bpb_pixel_dots / bpb_masked_pool (csrc/attn_pool.hip): a branch output IS an NHWC map.
+#include "bpb_common.h"
+
+#define LR_MAXB 8
+#define LR_MAXJ 12
+#define LR_TX 16          // channel quads per workgroup of the streaming kernels (x 16 pixel rows)
+#define LR_STATS_PX 512   // pixels per workgroup of the statistics pass (every split is a row of fp64 partials: 4 per 64x32 image)
+#define LR_DX_PX 128      // pixels per workgroup of the gradient pass
+
+// weight of source index `is` in the bilinear (align_corners) interpolation of target index `o`: the arithmetic of
+// bpb_bilinear_concat_multi_fwd (csrc/resample.hip), fp32 like ATen
+__device__ __forceinline__ float lr_tent(int o, int is, int nin, float scale)
+{
+    const float f = scale * o;
+    const int i0 = (int)f, i1 = i0 + (i0 < nin - 1);
+    const float l1 = f - i0, l0 = 1.f - l1;
+    return (i0 == is ? l0 : 0.f) + (i1 == is ? l1 : 0.f);
+}
+// conservative range of targets o with a non-zero weight on source `is`
+__device__ __forceinline__ void lr_range(int is, int nout, float scale, int& lo, int& hi)
+{
+    lo = 0;
+    hi = nout - 1;
+    if (scale > 0.f) {
+        const float inv = 1.f / scale;
+        lo = max(0, (int)floorf((is - 1) * inv) - 1);
+        hi = min(nout - 1, (int)ceilf((is + 1) * inv) + 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 9-tap Gram stencil (G x)[i][j] = sum_{di,dj} G_h[i][i+di] G_w[j][j+dj] x[i+di][j+dj] of one channel quad; the identity for a
+// branch at the map's own resolution
+#define LR_MAXDIM 256        // largest branch height / width whose band tables fit the kernels' LDS copy
+struct LrTables {            // LDS copy of a branch's band tables (the global ones cost a dependent load per tap)
+    float gh[LR_MAXDIM * 3], gw[LR_MAXDIM * 3], w1h[LR_MAXDIM], w1w[LR_MAXDIM];
+};
+__device__ __forceinline__ void lr_load_tables(LrTables& T, const BpbHeadBranch& B)
+{
+    for (int i = threadIdx.x; i < B.Hs * 3; i += blockDim.x) T.gh[i] = B.gh[i];
+    for (int i = threadIdx.x; i < B.Ws * 3; i += blockDim.x) T.gw[i] = B.gw[i];
+    for (int i = threadIdx.x; i < B.Hs; i += blockDim.x) T.w1h[i] = B.w1h[i];
+    for (int i = threadIdx.x; i < B.Ws; i += blockDim.x) T.w1w[i] = B.w1w[i];
+    __syncthreads();
+}
+__device__ __forceinline__ f32x4 lr_gram(const BpbHeadBranch& B, const LrTables& T, const float* xb, int i, int j, const f32x4 xc, bool ident)
+{
+    if (ident) return xc;
+    f32x4 gx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int di = -1; di <= 1; ++di) {
+        const int ii = i + di;
+        if (ii < 0 || ii >= B.Hs) continue;
+        const float gh = T.gh[i * 3 + di + 1];
+#pragma unroll
+        for (int dj = -1; dj <= 1; ++dj) {
+            const int jj = j + dj;
+            if (jj < 0 || jj >= B.Ws) continue;
+            const float g = gh * T.gw[j * 3 + dj + 1];
+            const f32x4 v = (di == 0 && dj == 0) ? xc : *(const f32x4*)(xb + ((long)ii * B.Ws + jj) * B.Cs);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gx[e] += g * v[e];
+        }
+    }
+    return gx;
+}
+
+// pixel splits of branch b when the largest branch is cut into PS pieces: about the same number of pixels per workgroup
+__host__ __device__ __forceinline__ int lr_branch_splits(int HWs, int HWmax, int PS)
+{
+    int p = (int)(((long)PS * HWs + HWmax - 1) / HWmax);
+    return p < 1 ? 1 : p;
+}
+
+// 1-D grid over (branch, image, pixel split, channel group): no empty workgroups.  Passed by value.
+struct LrGrid {
+    int begin[LR_MAXB + 1];      // first block of each branch
+    int psb[LR_MAXB];            // pixel splits of the branch
+    int ncg[LR_MAXB];            // channel groups (LR_TX quads each) of the branch
+};
+__device__ __forceinline__ void lr_locate(const LrGrid& g, int nb, int& b, int& n, int& ps, int& cg)
+{
+    b = 0;
+    for (int i = 1; i < nb; ++i)
+        if ((int)blockIdx.x >= g.begin[i]) b = i;
+    int r = (int)blockIdx.x - g.begin[b];
+    cg = r % g.ncg[b];
+    r /= g.ncg[b];
+    ps = r % g.psb[b];
+    n = r / g.psb[b];
+}
+
+// partials[(n * PS + ps)][0][c0 + c] = sum over the pixels q of split ps of w1[q] x[n][q][c]
+// partials[(n * PS + ps)][1][c0 + c] = sum ...                          of x[n][q][c] (G x)[n][q][c]
+// (the per-channel sum and sum of squares of the up-sampled branch over image n; consumed by bpb_bn_finalize; a branch with
+// fewer splits than PS writes zeros into its surplus rows)
+__global__ __launch_bounds__(256) void lr_stats_kernel(const BpbHeadBranch* __restrict__ br, LrGrid grid, int nb, int PS, int Ct,
+                                                       double* __restrict__ partials)
+{
+    __shared__ double red[256][2];
+    __shared__ LrTables T;
+    int bi, n, ps, cg;
+    lr_locate(grid, nb, bi, n, ps, cg);
+    const BpbHeadBranch B = br[bi];
+    const int c4 = B.Cs >> 2;
+    const int tx = c4 >= LR_TX ? LR_TX : c4, rows = 256 / tx;
+    const int cq = cg * tx + (threadIdx.x % tx), trow = threadIdx.x / tx;
+    lr_load_tables(T, B);
+    const int HWs = B.Hs * B.Ws;
+    const int psb = grid.psb[bi];
+    const int per = (HWs + psb - 1) / psb, q0 = ps * per, q1 = min(HWs, q0 + per);
+    const bool ident = B.sh == 1.f && B.sw == 1.f;
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    if (cq < c4 && trow < rows) {
+        const float* xb = B.x + (long)n * HWs * B.Cs + cq * 4;
+        for (int q = q0 + trow; q < q1; q += rows) {
+            const int i = q / B.Ws, j = q - i * B.Ws;
+            const f32x4 xc = *(const f32x4*)(xb + (long)q * B.Cs);
+            const f32x4 gx = lr_gram(B, T, xb, i, j, xc, ident);
+            const float w1 = ident ? 1.f : T.w1h[i] * T.w1w[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s1[e] += (double)(w1 * xc[e]);
+                s2[e] += (double)(xc[e] * gx[e]);
+            }
+        }
+    }
+    // combine the pixel rows in a fixed order
+    for (int e = 0; e < 4; ++e) {
+        red[threadIdx.x][0] = s1[e];
+        red[threadIdx.x][1] = s2[e];
+        __syncthreads();
+        if (trow == 0 && cq < c4) {
+            double a = 0.0, b = 0.0;
+            for (int r = 0; r < rows; ++r) {
+                a += red[r * tx + (threadIdx.x % tx)][0];
+                b += red[r * tx + (threadIdx.x % tx)][1];
+            }
+            const long row = (long)n * PS + ps;                 // (rows ps >= psb of this branch's columns stay zero: host)
+            partials[(row * 2 + 0) * Ct + B.c0 + cq * 4 + e] = a;
+            partials[(row * 2 + 1) * Ct + B.c0 + cq * 4 + e] = b;
+        }
+        __syncthreads();
+    }
+}
+
+// out[n][p][j] = bias[j] + sum_b bilinear_b(lb_b[n][.][j])(p)        lb_b: [N][Hs*Ws][J], out: [N][H*W][J]
+__global__ __launch_bounds__(256) void lr_upsample_sum_kernel(const BpbHeadBranch* __restrict__ br, int nb, const float* const* __restrict__ lb,
+                                                              const float* __restrict__ bias, float* __restrict__ out, int N, int H,
+                                                              int W, int J)
+{
+    const long total = (long)N * H * W * J;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+        const int j = (int)(i % J);
+        long t = i / J;
+        const int w = (int)(t % W);
+        t /= W;
+        const int h = (int)(t % H);
+        const long n = t / H;
+        float v = bias ? bias[j] : 0.f;
+        for (int b = 0; b < nb; ++b) {
+            const BpbHeadBranch B = br[b];
+            const float fh = B.sh * h, fw = B.sw * w;
+            const int h0 = (int)fh, w0 = (int)fw;
+            const int h1 = h0 + (h0 < B.Hs - 1), w1 = w0 + (w0 < B.Ws - 1);
+            const float lh1 = fh - h0, lw1 = fw - w0, lh0 = 1.f - lh1, lw0 = 1.f - lw1;
+            const float* s = lb[b] + n * (long)B.Hs * B.Ws * J + j;
+            v += lh0 * (lw0 * s[((long)h0 * B.Ws + w0) * J] + lw1 * s[((long)h0 * B.Ws + w1) * J]) +
+                 lh1 * (lw0 * s[((long)h1 * B.Ws + w0) * J] + lw1 * s[((long)h1 * B.Ws + w1) * J]);
+        }
+        out[i] = v;
+    }
+}
+
+// out_b[n][j][q] = scale(n, j) * sum_p U_b[p][q] a[n][j][p]      a: [N][J][H*W], out_b: [N][J][Hs*Ws]
+// scale: 1, or (zinv given) the pooling normalisation of row j: 1/HW for j < 3, |zinv[n][j]| for the part rows
+__global__ __launch_bounds__(256) void lr_adjoint_kernel(const BpbHeadBranch* __restrict__ br, const float* __restrict__ a,
+                                                         const float* __restrict__ zinv, float* const* __restrict__ outs, int N, int J,
+                                                         int H, int W)
+{
+    const BpbHeadBranch B = br[blockIdx.y];
+    float* out = outs[blockIdx.y];
+    const int HWs = B.Hs * B.Ws;
+    const long total = (long)N * J * HWs;
+    const float inv_hw = 1.f / (float)(H * W);
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+        const int q = (int)(i % HWs);
+        const long nj = i / HWs;
+        const int j = (int)(nj % J);
+        const int is = q / B.Ws, js = q - is * B.Ws;
+        const float* ap = a + nj * (long)H * W;
+        int hlo, hhi, wlo, whi;
+        lr_range(is, H, B.sh, hlo, hhi);
+        lr_range(js, W, B.sw, wlo, whi);
+        if (B.Hs == H) { hlo = hhi = is; }
+        if (B.Ws == W) { wlo = whi = js; }
+        float s = 0.f;
+        for (int h = hlo; h <= hhi; ++h) {
+            const float wh = B.Hs == H ? 1.f : lr_tent(h, is, B.Hs, B.sh);
+            if (wh == 0.f) continue;
+            float r = 0.f;
+            for (int w = wlo; w <= whi; ++w) {
+                const float ww = B.Ws == W ? 1.f : lr_tent(w, js, B.Ws, B.sw);
+                r += ww * ap[(long)h * W + w];
+            }
+            s += wh * r;
+        }
+        const float sc = zinv ? (j < 3 ? inv_hw : fabsf(zinv[nj])) : 1.f;
+        out[i] = s * sc;
+    }
+}
+
+// dx_b[n][q][c] (+)= sum_j scale(n, j) pmb_b[n][j][q] G[n][j][c0 + c]
+//                  + gamma invstd ( sum_k dld_b[n][k][q] Wc[k][c0 + c] - k1 w1[q] - invstd k2 ((G x)[n][q][c] - mean w1[q]) )
+// = U_b^T applied to the gradient of the virtual map (csrc/attn_pool.hip, bpb_head_bwd_dx), channel block of branch b.
+// pmb_b = the pooling masks resampled to the branch in the forward pass; scale = their normalisation (1/HW for the global /
+// fg / bg rows, |zinv| for the part rows) -- folded into the G rows held in registers.
+template <int J, int K1>
+__global__ __launch_bounds__(256) void lr_dx_kernel(const BpbHeadBranch* __restrict__ br, LrGrid grid, int nb, const float* __restrict__ G_,
+                                                    const float* const* __restrict__ pmb, const float* __restrict__ zinv,
+                                                    const float* const* __restrict__ dld, const float* __restrict__ Wc,
+                                                    const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                    const float* __restrict__ invstd, const float* __restrict__ k1,
+                                                    const float* __restrict__ k2, int Ct, float inv_hw)
+{
+    constexpr int RP = (J + K1 + 3) & ~3;                        // per-pixel record: mask rows, dlogit rows, padding
+    __shared__ LrTables T;
+    __shared__ __attribute__((aligned(16))) float rec[LR_DX_PX * RP];
+    int bi, n, ps, cg;
+    lr_locate(grid, nb, bi, n, ps, cg);
+    const BpbHeadBranch B = br[bi];
+    const int c4 = B.Cs >> 2;
+    const int tx = c4 >= LR_TX ? LR_TX : c4, rows = 256 / tx;
+    const int HWs = B.Hs * B.Ws;
+    const int psb = grid.psb[bi];
+    const int per = (HWs + psb - 1) / psb, q0 = ps * per, q1 = min(HWs, q0 + per);       // per <= LR_DX_PX (host)
+    const bool cls = dld != nullptr;
+    {   // the pixel coefficients of this block: read once, coalesced along the pixels, as records [pixel][J + K1]
+        const float* cf = pmb[bi] + (long)n * J * HWs;
+        const float* dl = cls ? dld[bi] + (long)n * K1 * HWs : nullptr;
+        for (int i = threadIdx.x; i < (J + K1) * per; i += 256) {
+            const int j = i / per, q = q0 + (i - j * per);
+            float v = 0.f;
+            if (q < q1) v = j < J ? cf[(long)j * HWs + q] : (cls ? dl[(long)(j - J) * HWs + q] : 0.f);
+            rec[(i - j * per) * RP + j] = v;
+        }
+    }
+    lr_load_tables(T, B);                                        // (ends with the barrier that also publishes `rec`)
+    const int cq = cg * tx + (threadIdx.x % tx), trow = threadIdx.x / tx;
+    if (cq >= c4 || trow >= rows) return;
+    const int cc = B.c0 + cq * 4;
+    const bool ident = B.sh == 1.f && B.sw == 1.f;
+    f32x4 g[J], wk[K1 > 0 ? K1 : 1];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const float sc = j < 3 ? inv_hw : fabsf(zinv[(long)n * J + j]);
+        g[j] = *(const f32x4*)(G_ + ((long)n * J + j) * Ct + cc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[j][e] *= sc;
+    }
+    f32x4 gi = {0.f, 0.f, 0.f, 0.f}, mu = gi, is = gi, c1 = gi, c2 = gi;
+    if (cls) {
+#pragma unroll
+        for (int k = 0; k < K1; ++k) wk[k] = *(const f32x4*)(Wc + (long)k * Ct + cc);
+        const f32x4 ga = *(const f32x4*)(gamma + cc);
+        mu = *(const f32x4*)(mean + cc);
+        is = *(const f32x4*)(invstd + cc);
+        c1 = *(const f32x4*)(k1 + cc);
+        c2 = *(const f32x4*)(k2 + cc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gi[e] = ga[e] * is[e];
+    }
+    const float* xb = B.x + (long)n * HWs * B.Cs + cq * 4;
+    float* dxb = B.dx + (long)n * HWs * B.Cs + cq * 4;
+    for (int q = q0 + trow; q < q1; q += rows) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f}, dz = {0.f, 0.f, 0.f, 0.f};
+        const float* r = rec + (q - q0) * RP;
+#pragma unroll
+        for (int jq = 0; jq < RP / 4; ++jq) {
+            const f32x4 rv = *(const f32x4*)(r + jq * 4);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = jq * 4 + jj;
+                if (j < J) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += rv[jj] * g[j][e];
+                } else if (j < J + K1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dz[e] += rv[jj] * wk[j - J][e];
+                }
+            }
+        }
+        if (cls) {
+            const int i = q / B.Ws, jx = q - i * B.Ws;
+            const f32x4 xc = *(const f32x4*)(xb + (long)q * B.Cs);
+            const f32x4 gx = lr_gram(B, T, xb, i, jx, xc, ident);
+            const float w1 = ident ? 1.f : T.w1h[i] * T.w1w[jx];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += gi[e] * (dz[e] - c1[e] * w1 - is[e] * c2[e] * (gx[e] - mu[e] * w1));
+        }
+        if (B.accumulate) {
+            const f32x4 old = *(const f32x4*)(dxb + (long)q * B.Cs);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += old[e];
+        }
+        *(f32x4*)(dxb + (long)q * B.Cs) = o;
+    }
+}
+
+static int lr_grid(long total)
+{
+    long g = (total + 255) / 256;
+    if (g > 4096) g = 4096;
+    return g < 1 ? 1 : (int)g;
+}
+
+static int lr_check(const BpbHeadBranch* h_br, int nb, const char* who)
+{
+    BPB_REQUIRE(nb >= 1 && nb <= LR_MAXB, "%s: %d branches (1..%d)", who, nb, LR_MAXB);
+    for (int b = 0; b < nb; ++b)
+        BPB_REQUIRE(h_br[b].Cs % 4 == 0 && h_br[b].Hs >= 1 && h_br[b].Ws >= 1 && h_br[b].c0 % 4 == 0 && h_br[b].Hs <= LR_MAXDIM &&
+                        h_br[b].Ws <= LR_MAXDIM, "%s: branch %d: bad shape", who, b);
+    return 0;
+}
+
+// pixel splits of the LARGEST branch (the others get proportionally fewer, lr_branch_splits): ~64 pixels per workgroup
+static int lr_hwmax(const BpbHeadBranch* h_br, int nb)
+{
+    int m = 1;
+    for (int b = 0; b < nb; ++b) m = m > h_br[b].Hs * h_br[b].Ws ? m : h_br[b].Hs * h_br[b].Ws;
+    return m;
+}
+static int lr_splits(const BpbHeadBranch* h_br, int nb, int px_per_block)
+{
+    int ps = bpb_cdiv(lr_hwmax(h_br, nb), px_per_block);
+    return ps < 1 ? 1 : (ps > 64 ? 64 : ps);
+}
+static LrGrid lr_make_grid(const BpbHeadBranch* h_br, int nb, int N, int px_per_block, int* nblocks)
+{
+    LrGrid g;
+    int blk = 0;
+    for (int b = 0; b < nb; ++b) {
+        g.begin[b] = blk;
+        g.psb[b] = bpb_cdiv(h_br[b].Hs * h_br[b].Ws, px_per_block);
+        g.ncg[b] = bpb_cdiv(h_br[b].Cs >> 2, LR_TX);
+        blk += N * g.psb[b] * g.ncg[b];
+    }
+    for (int b = nb; b <= LR_MAXB; ++b) g.begin[b] = blk;
+    *nblocks = blk;
+    return g;
+}
+
+extern "C" {
+
+// rows of `partials` ([rows][2][Ct] doubles) that bpb_lowres_stats writes for a batch of N images
+int bpb_lowres_stats_rows(const BpbHeadBranch* h_br, int nb, int N, int* rows_out)
+{
+    if (int rc = lr_check(h_br, nb, "bpb_lowres_stats_rows")) return rc;
+    *rows_out = N * lr_splits(h_br, nb, LR_STATS_PX);
+    return 0;
+}
+
+int bpb_lowres_stats(const BpbHeadBranch* d_br, const BpbHeadBranch* h_br, int nb, int N, int Ct, double* partials, hipStream_t stream)
+{
+    if (int rc = lr_check(h_br, nb, "bpb_lowres_stats")) return rc;
+    int nblocks = 0;
+    const LrGrid g = lr_make_grid(h_br, nb, N, LR_STATS_PX, &nblocks);
+    // (rows [psb, PS) of a branch with fewer splits are never written: the caller zero-fills `partials` once)
+    hipLaunchKernelGGL(lr_stats_kernel, dim3(nblocks), dim3(256), 0, stream, d_br, g, nb, lr_splits(h_br, nb, LR_STATS_PX), Ct, partials);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_lowres_upsample_sum(const BpbHeadBranch* d_br, const BpbHeadBranch* h_br, int nb, const float* const* d_lb, const float* bias,
+                            float* out, int N, int H, int W, int J, hipStream_t stream)
+{
+    if (int rc = lr_check(h_br, nb, "bpb_lowres_upsample_sum")) return rc;
+    hipLaunchKernelGGL(lr_upsample_sum_kernel, dim3(lr_grid((long)N * H * W * J)), dim3(256), 0, stream, d_br, nb, d_lb, bias, out, N, H, W, J);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_lowres_adjoint(const BpbHeadBranch* d_br, const BpbHeadBranch* h_br, int nb, const float* a, const float* zinv,
+                       float* const* d_outs, int N, int J, int H, int W, hipStream_t stream)
+{
+    if (int rc = lr_check(h_br, nb, "bpb_lowres_adjoint")) return rc;
+    long most = 0;
+    for (int b = 0; b < nb; ++b) most = most > (long)N * J * h_br[b].Hs * h_br[b].Ws ? most : (long)N * J * h_br[b].Hs * h_br[b].Ws;
+    hipLaunchKernelGGL(lr_adjoint_kernel, dim3(lr_grid(most), nb), dim3(256), 0, stream, d_br, a, zinv, d_outs, N, J, H, W);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_lowres_dx(const BpbHeadBranch* d_br, const BpbHeadBranch* h_br, int nb, int N, int J, int K1, int Ct, int HW, const float* G,
+                  const float* const* d_pmb, const float* zinv, const float* const* d_dld, const float* Wc, const float* gamma,
+                  const float* mean, const float* invstd, const float* k1, const float* k2, hipStream_t stream)
+{
+    if (int rc = lr_check(h_br, nb, "bpb_lowres_dx")) return rc;
+    BPB_REQUIRE(J == K1 + 2 && K1 >= 2 && K1 <= 9, "bpb_lowres_dx: J=%d K+1=%d", J, K1);
+    int nblocks = 0;
+    const LrGrid g = lr_make_grid(h_br, nb, N, LR_DX_PX, &nblocks);
+#define LR_DX(KK) \
+    hipLaunchKernelGGL((lr_dx_kernel<KK + 2, KK>), dim3(nblocks), dim3(256), 0, stream, d_br, g, nb, G, d_pmb, zinv, d_dld, Wc, gamma, mean, \
+                       invstd, k1, k2, Ct, 1.f / (float)HW)
+    switch (K1) {
+        case 2: LR_DX(2); break;
+        case 3: LR_DX(3); break;
+        case 4: LR_DX(4); break;
+        case 5: LR_DX(5); break;
+        case 6: LR_DX(6); break;
+        case 7: LR_DX(7); break;
+        case 8: LR_DX(8); break;
+        case 9: LR_DX(9); break;
+    }
+#undef LR_DX
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+}   // extern "C"

@@ -44,8 +44,13 @@ class ImagePartBasedEngine:
     def __init__(self, model, optimizer=None, losses_weights=None, loss_name='part_averaged_triplet_loss', margin=0.3,
                  mask_filtering_training=False, mask_filtering_testing=True, dist_combine_strat='mean',
                  batch_size_pairwise_dist_matrix=500, test_embeddings=('bn_foreg', 'parts'), scheduler=None, use_gpu=True,
-                 process_group=None, distributed=False, writer=None, bucket_bytes=16 << 20):
+                 process_group=None, distributed=False, writer=None, bucket_bytes=16 << 20, need_spatial_features=False):
         self.model = model
+        # Neither the training step nor the evaluation reads `spatial_features` (the reference engine only hands it to its
+        # feature-map visualisation, part_based_engine.py:82-84): the model then runs its head on the HRNet branch outputs and
+        # never writes the 1 GB concatenated map (csrc/head_lowres.hip).  `need_spatial_features=True` restores the output.
+        if hasattr(model, 'materialize_spatial_features'):
+            model.materialize_spatial_features = bool(need_spatial_features)
         self.optimizer = optimizer if optimizer is not None else FusedAdam(model)
         self.scheduler = scheduler
         self.losses_weights = losses_weights if losses_weights is not None else DEFAULT_WEIGHTS

@@ -946,6 +946,9 @@ class Net:
                         byt += 4.0 * (a.N * out.H * out.W * a.C + a.buf.numel())
                     bwd.add(self._single(nv.OP_BILINEAR_MULTI_BWD, 'bilinear_concat_multi_bwd', 0, byt, ints=(len(srcs),),
                                          ptrs=(self._dev_struct(host), C.addressof(host))))
+                    # (the head without the concatenated map writes the source gradients itself, with the same flags)
+                    self.concat_bwd_accumulate = getattr(self, 'concat_bwd_accumulate', {})
+                    self.concat_bwd_accumulate[id(out)] = [int(host[q].accumulate) for q in range(len(srcs))]
                     continue
                 for a, off in zip(srcs, offs):
                     a.ensure_grad(self)

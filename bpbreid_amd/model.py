@@ -14,6 +14,8 @@ Execution model (MI355X-first, not a module-by-module translation):
 There is no PyTorch/CPU fallback: without the HIP library or a GPU, forward raises.
 """
 import ctypes as C
+import os
+import types
 
 import torch
 import torch.nn as nn
@@ -248,6 +250,11 @@ class BPBreID(nn.Module):
         self._arena = None
         self._plans = {}
         self._anchor = None
+        # True (default, the reference's contract): `spatial_features` is returned, i.e. the concatenated HRNet map is written to
+        # HBM (1 GB at batch 64) and the head streams it.  False: the head works on the branch outputs (csrc/head_lowres.hip, same
+        # results up to summation order) and `spatial_features` is None -- what ImagePartBasedEngine sets, which never reads it
+        # (the reference only feeds it to its feature-map visualisation, part_based_engine.py:82-84).
+        self.materialize_spatial_features = True
 
     # ---------------------------------------------------------------- flat arenas
     def flatten_parameters(self):
@@ -368,6 +375,11 @@ class _ModelPlan:
         self.net, self.feats = net, feats
         feats.ensure_grad(net)
         self.generation = 0
+        self.lr = None                       # state of the head without the concatenated map (None: not applicable)
+        self._lowres_srcs = None
+        for kind_, pay_ in net.nodes:
+            if kind_ == 'concat' and pay_[0] is feats and net.multi_concat(*pay_):
+                self._lowres_srcs = pay_[1]
         self.learnable = bool(model.learnable_attention_enabled)
         self.after_pooling = bool(model.after_pooling_dim_reduce)
         K, D, Cc = model.parts_num, model.dim_reduce_output, feats.C
@@ -437,6 +449,82 @@ class _ModelPlan:
         else:
             self.cls_p = [(_Bn(pc.bn, False), _Lin(pc.classifier)) for pc in m.parts_identity_classifier]
 
+    # ---------------------------------------------------------------- head without the concatenated map
+    @staticmethod
+    def _bilinear_tables(nout, nin):
+        """fp32 replica of the align_corners interpolation matrix U [nout][nin] of csrc/resample.hip (scale = (nin-1)/(nout-1)
+        in fp32, weights l1 = f - i0, l0 = 1 - l1) -> (scale, column sums [nin], bands (i-1, i, i+1) of U^T U [nin][3])."""
+        import numpy as np
+        f32 = np.float32
+        scale = f32(nin - 1) / f32(nout - 1) if nout > 1 else f32(0)
+        U = np.zeros((nout, nin), dtype=np.float64)
+        for o in range(nout):
+            f = f32(scale * f32(o))
+            i0 = int(f)
+            i1 = i0 + (1 if i0 < nin - 1 else 0)
+            l1 = f32(f - f32(i0))
+            l0 = f32(f32(1) - l1)
+            U[o, i0] += float(l0)
+            U[o, i1] += float(l1)
+        G = U.T @ U
+        bands = np.zeros((nin, 3), dtype=np.float32)
+        for i in range(nin):
+            for d in (-1, 0, 1):
+                if 0 <= i + d < nin:
+                    bands[i, d + 1] = G[i, i + d]
+        assert np.abs(np.triu(G, 2)).max() == 0.0
+        return float(scale), U.sum(0).astype(np.float32), bands
+
+    def _init_lowres(self):
+        net, dev, n = self.net, self.pooled.device, self.N
+        srcs = self._lowres_srcs
+        K1, J, Cc = self.K1, self.J, self.C
+        lr = types.SimpleNamespace()
+        nb = lr.nb = len(srcs)
+        flags = getattr(net, 'concat_bwd_accumulate', {}).get(id(self.feats), [0] * nb)
+        lr.host = (nv.HeadBranch * nb)()
+        lr.keep = []
+        c0 = 0
+        for b, a in enumerate(srcs):
+            sh, w1h, gh = self._bilinear_tables(self.Hf, a.H)
+            sw, w1w, gw = self._bilinear_tables(self.Wf, a.W)
+            tabs = [torch.from_numpy(t).to(dev) for t in (gh, gw, w1h, w1w)]
+            lr.keep += tabs
+            h = lr.host[b]
+            h.x, h.dx = a.buf.data_ptr(), a.ensure_grad(net).data_ptr()
+            h.gh, h.gw, h.w1h, h.w1w = (t.data_ptr() for t in tabs)
+            h.Hs, h.Ws, h.Cs, h.c0, h.sh, h.sw, h.accumulate = a.H, a.W, a.C, c0, sh, sw, flags[b]
+            c0 += a.C
+        assert c0 == Cc
+        lr.dev = net._dev_struct(lr.host)
+        lr.srcs = srcs
+        f = lambda *sh_: _f32(*sh_, device=dev)
+        jm = max(J, K1 + 1)
+        lr.lb = [f(n, a.H * a.W, K1 + 1) for a in srcs]            # per-branch logits / gradient dots
+        lr.pmb = [f(n, jm, a.H * a.W) for a in srcs]              # masks resampled to the branch (adjoint)
+        lr.dld = [f(n, K1, a.H * a.W) for a in srcs]
+        ptrs = lambda ts: torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64, device=dev)
+        lr.d_lb, lr.d_pmb, lr.d_dld = ptrs(lr.lb), ptrs(lr.pmb), ptrs(lr.dld)
+        lr.nchunks, lr.part = [], []
+        for a in srcs:
+            nch = C.c_int(0)
+            nv.call('bpb_masked_pool', None, None, None, n, a.H * a.W, a.C, J, C.byref(nch), None)
+            lr.nchunks.append(nch.value)
+            lr.part.append(f(n * nch.value * jm * a.C))
+        rows = C.c_int(0)
+        nv.call('bpb_lowres_stats_rows', lr.host, nb, n, C.byref(rows))
+        lr.stat_rows = rows.value
+        lr.stat_partials = torch.zeros(rows.value * 2 * Cc, device=dev, dtype=torch.float64)    # (surplus rows of the small branches stay 0)
+        # the launches of the plans that only exist for the materialised map
+        find = lambda plan, label: [k for k, m_ in enumerate(plan[2]) if m_['label'] == label]
+        lr.cut = {}
+        for name, plan in (('train', net.plan_train), ('eval', net.plan_eval)):
+            at = find(plan, 'bilinear_concat_multi_fwd')
+            assert at == [plan[1] - 1], 'the concatenation is expected to be the last launch of the forward plan'
+            lr.cut[name] = at[0]
+        assert find(net.plan_bwd, 'bilinear_concat_multi_bwd') == [0], 'the up-sampling backward is expected to open the backward plan'
+        self.lr = lr
+
     def bucket_schedule(self, buckets, grad_arena):
         """[(launch index of plan_bwd | -1, [bucket ids])] in launch order: bucket b = arena elements [off, off + n) is complete
         once the launch with that index has been enqueued (-1: before the backbone plan starts -- buckets that hold only
@@ -482,15 +570,32 @@ class _ModelPlan:
         net.in_buf.copy_(images)                       # boundary copy (same device); H2D is the caller's business
         x = self.feats.buf
         fresh = None
-        if not training:
+        # head on the branch outputs, the concatenated map is never written (csrc/head_lowres.hip)?
+        low = (not m.materialize_spatial_features) and self._lowres_srcs is not None and os.environ.get('BPB_LOWRES_HEAD', '1') != '0'
+        if low and self.lr is None:
+            self._init_lowres()
+        self.low = low
+        lr = self.lr if low else None
+        if low:
+            net.run(net.plan_train if training else net.plan_eval, 0, lr.cut['train' if training else 'eval'])
+            if training:
+                m._arena['ibuf'] += 1
+            x = None
+        elif not training:
             # eval hands out a fresh feature map per call (API boundary, below): let the plan's concatenation write it directly
             # instead of cloning the 1 GB plan buffer afterwards
             fresh = torch.empty_like(x)
             if net.redirect_eval_concat(self.feats, fresh.data_ptr()):
                 x = fresh
-        net.run(net.plan_train if training else net.plan_eval)
-        if training:
+        if low:
+            pass
+        elif training:
+            net.run(net.plan_train)
             m._arena['ibuf'] += 1                      # every BatchNorm's num_batches_tracked
+        else:
+            net.run(net.plan_eval)
+        if low or training:
+            pass
         elif x is not fresh:
             fresh.copy_(x)                             # (backbones whose map is a plain convolution output: ResNet-50, 67 MB)
             x = fresh
@@ -501,7 +606,10 @@ class _ModelPlan:
         if self.learnable:
             if training:
                 sp = getattr(self.feats, 'stats_partials', None)
-                if sp is not None:       # the concatenation kernel of the plan already emitted the (sum, sum^2) partials
+                if low:                  # sums over the virtual map from the branch outputs (9-tap Gram stencil)
+                    partials, nparts = lr.stat_partials, lr.stat_rows
+                    nv.call('bpb_lowres_stats', lr.dev.data_ptr(), lr.host, lr.nb, n, Cc, partials.data_ptr(), s())
+                elif sp is not None:     # the concatenation kernel of the plan already emitted the (sum, sum^2) partials
                     partials, nparts = sp, self.feats.stats_nblocks
                 else:
                     partials, nparts = self.pix_partials, self.nstat_blocks
@@ -515,8 +623,15 @@ class _ModelPlan:
                         pc.bn.running_var.data_ptr(), BN_EPS, self.pix_scale.data_ptr(), self.pix_shift.data_ptr(), s())
             nv.call('bpb_fold_bn', pc.classifier.weight.data_ptr(), pc.classifier.bias.data_ptr(), self.pix_scale.data_ptr(),
                     self.pix_shift.data_ptr(), self.pix_wf.data_ptr(), self.pix_bf.data_ptr(), K1, Cc, s())
-            nv.call('bpb_pixel_dots', x.data_ptr(), self.pix_wf.data_ptr(), 0, self.pix_bf.data_ptr(), self.logits_pm.data_ptr(),
-                    n, HW, Cc, K1, s())
+            if low:                  # W M = sum_b U_b (W_b x_b): K+1 logit channels per branch, then one up-sampling sum
+                for b, a in enumerate(lr.srcs):
+                    nv.call('bpb_pixel_dots', a.buf.data_ptr(), self.pix_wf.data_ptr() + 4 * lr.host[b].c0, 0, Cc, None,
+                            lr.lb[b].data_ptr(), n, a.H * a.W, a.C, K1, s())
+                nv.call('bpb_lowres_upsample_sum', lr.dev.data_ptr(), lr.host, lr.nb, lr.d_lb.data_ptr(), self.pix_bf.data_ptr(),
+                        self.logits_pm.data_ptr(), n, self.Hf, self.Wf, K1, s())
+            else:
+                nv.call('bpb_pixel_dots', x.data_ptr(), self.pix_wf.data_ptr(), 0, Cc, self.pix_bf.data_ptr(),
+                        self.logits_pm.data_ptr(), n, HW, Cc, K1, s())
             nv.call('bpb_softmax_masks', self.logits_pm.data_ptr(), self.scores.data_ptr(), self.probs.data_ptr(),
                     self.pm.data_ptr(), self.argpart.data_ptr(), self.argcls.data_ptr(), n, HW, K1, s())
             if seg_mode:
@@ -531,9 +646,17 @@ class _ModelPlan:
         self.binary = bool(binary)
         nv.call('bpb_visibility', self.probs.data_ptr(), self.argcls.data_ptr(), self.vis.data_ptr(), self.fgvis.data_ptr(),
                 n, HW, K1, 1 if binary else 0, None if binary else self.argpix.data_ptr(), s())
-        nv.call('bpb_masked_pool', x.data_ptr(), self.pm.data_ptr(), self.pool_part.data_ptr(), n, HW, Cc, J, None, s())
-        nv.call('bpb_pool_finalize', self.pool_part.data_ptr(), self.pm.data_ptr(), self.pooled.data_ptr(),
-                self.zinv.data_ptr(), n, self.nchunks, J, HW, Cc, 1 if m.parts_gap else 0, s())
+        if low:                      # sum_p a[p] M[p] = sum_q (U_b^T a)[q] x_b[q]: the masks go DOWN to the branch resolutions
+            nv.call('bpb_lowres_adjoint', lr.dev.data_ptr(), lr.host, lr.nb, self.pm.data_ptr(), None, lr.d_pmb.data_ptr(), n, J,
+                    self.Hf, self.Wf, s())
+            for b, a in enumerate(lr.srcs):
+                nv.call('bpb_masked_pool', a.buf.data_ptr(), lr.pmb[b].data_ptr(), lr.part[b].data_ptr(), n, a.H * a.W, a.C, J, None, s())
+                nv.call('bpb_pool_finalize', lr.part[b].data_ptr(), self.pm.data_ptr(), self.pooled.data_ptr(), self.zinv.data_ptr(),
+                        n, lr.nchunks[b], J, HW, a.C, 1 if m.parts_gap else 0, lr.host[b].c0, Cc, s())
+        else:
+            nv.call('bpb_masked_pool', x.data_ptr(), self.pm.data_ptr(), self.pool_part.data_ptr(), n, HW, Cc, J, None, s())
+            nv.call('bpb_pool_finalize', self.pool_part.data_ptr(), self.pm.data_ptr(), self.pooled.data_ptr(),
+                    self.zinv.data_ptr(), n, self.nchunks, J, HW, Cc, 1 if m.parts_gap else 0, 0, Cc, s())
         # ---- after-pooling dim reduce (Linear + BN1d + ReLU); pooled rows: 0 global, 1 fg, 2 bg, 3.. parts
         o = {}
         f = lambda *sh: _f32(*sh, device=dev)
@@ -580,7 +703,7 @@ class _ModelPlan:
         # 1 GB feature map is the exception in TRAINING mode: it is returned as a logical-NCHW view of the NHWC plan buffer,
         # valid until the next forward of this shape.
         pix = self.scores.clone() if self.learnable else torch.empty(0, device=dev)
-        feats_nchw = x.permute(0, 3, 1, 2)
+        feats_nchw = x.permute(0, 3, 1, 2) if x is not None else torch.empty(0, device=dev)      # (not materialised: None outside)
         # visibility scores as outputs of the autograd node: continuous scores are differentiable (the reference back-propagates
         # through amax, bpbreid.py:186-189); binary ones are constants
         return (o['g'], o['b'], o['f'], o['p'], e['g'][0], e['b'][0], e['f'][0], e['c'][0], bn_p,
@@ -605,7 +728,7 @@ class _ModelPlan:
         fg = pm[:, 1]
         bgm = pm[:, 2] > 0.5 if self.seg_mode == 2 else pm[:, 2]    # 'hard': the reference's background mask is ~target (bool)
         masks = {GLOBAL: pm[:, 0], BACKGROUND: bgm, FOREGROUND: fg, CONCAT_PARTS: fg, PARTS: pm[:, 3:]}
-        return emb, visd, ids, (pix if self.learnable else None), feats, masks
+        return emb, visd, ids, (pix if self.learnable else None), (None if self.low else feats), masks
 
     # ---------------------------------------------------------------- backward
     def backward(self, grads):
@@ -720,9 +843,17 @@ class _ModelPlan:
         gfe = g['feats']
         if gfe is not None:
             raise NotImplementedError('external gradient on spatial_features')
+        low, lr = self.low, self.lr
         if self.learnable:
             nv.call('bpb_rowdot', gpool.data_ptr(), self.pooled.data_ptr(), self.gp.data_ptr(), n * J, Cc, s())
-            nv.call('bpb_pixel_dots', x.data_ptr(), gp_ptr + Cc * 4, J * Cc, None, self.Dd.data_ptr(), n, HW, Cc, K1 + 1, s())
+            if low:
+                for b, a in enumerate(lr.srcs):
+                    nv.call('bpb_pixel_dots', a.buf.data_ptr(), gp_ptr + 4 * (Cc + lr.host[b].c0), J * Cc, Cc, None, lr.lb[b].data_ptr(),
+                            n, a.H * a.W, a.C, K1 + 1, s())
+                nv.call('bpb_lowres_upsample_sum', lr.dev.data_ptr(), lr.host, lr.nb, lr.d_lb.data_ptr(), None, self.Dd.data_ptr(), n,
+                        self.Hf, self.Wf, K1 + 1, s())
+            else:
+                nv.call('bpb_pixel_dots', x.data_ptr(), gp_ptr + Cc * 4, J * Cc, Cc, None, self.Dd.data_ptr(), n, HW, Cc, K1 + 1, s())
             gpix = g['pix'].contiguous() if g['pix'] is not None else None
             # gradients of the continuous visibility scores (vis[n][k] = max_p prob_k, fgvis[n] = max_k vis[n][k]) join dlogit
             dvis = g['vis'].to(torch.float32).contiguous() if (not self.binary and g['vis'] is not None) else None
@@ -731,28 +862,51 @@ class _ModelPlan:
             nv.call('bpb_head_bwd_dlogits', self.Dd.data_ptr(), self.probs.data_ptr(), self.argpart.data_ptr(), self.zinv.data_ptr(),
                     self.gp.data_ptr(), gpix.data_ptr() if gpix is not None else None, self.dlogit.data_ptr(), self.lpart.data_ptr(),
                     None, n, HW, K1, nv.ptr(dvis), nv.ptr(dfg), self.argpix.data_ptr() if use_arg else None, s())
-            nv.call('bpb_masked_pool', x.data_ptr(), self.dlogit.data_ptr(), self.pool_part.data_ptr(), n, HW, Cc, K1, None, s())
-            nv.call('bpb_head_bwd_params', self.pool_part.data_ptr(), n * self.nchunks, self.lpart.data_ptr(), self.nlpart, n, HW, K1, Cc,
-                    pc.classifier.weight.data_ptr(), pc.bn.weight.data_ptr(), pc.bn.bias.data_ptr(), self.pix_mean.data_ptr(),
-                    self.pix_invstd.data_ptr(), pc.classifier.weight.grad.data_ptr(), pc.classifier.bias.grad.data_ptr(),
-                    pc.bn.weight.grad.data_ptr(), pc.bn.bias.grad.data_ptr(), self.k1.data_ptr(), self.k2.data_ptr(), 0, s())
+            if low:
+                nv.call('bpb_lowres_adjoint', lr.dev.data_ptr(), lr.host, lr.nb, self.dlogit.data_ptr(), None, lr.d_dld.data_ptr(), n, K1,
+                        self.Hf, self.Wf, s())
+                for b, a in enumerate(lr.srcs):
+                    o4 = 4 * lr.host[b].c0
+                    nv.call('bpb_masked_pool', a.buf.data_ptr(), lr.dld[b].data_ptr(), lr.part[b].data_ptr(), n, a.H * a.W, a.C, K1, None, s())
+                    nv.call('bpb_head_bwd_params', lr.part[b].data_ptr(), n * lr.nchunks[b], self.lpart.data_ptr(), self.nlpart, n, HW, K1,
+                            a.C, Cc, pc.classifier.weight.data_ptr() + o4, pc.bn.weight.data_ptr() + o4, pc.bn.bias.data_ptr() + o4,
+                            self.pix_mean.data_ptr() + o4, self.pix_invstd.data_ptr() + o4, pc.classifier.weight.grad.data_ptr() + o4,
+                            pc.classifier.bias.grad.data_ptr(), pc.bn.weight.grad.data_ptr() + o4, pc.bn.bias.grad.data_ptr() + o4,
+                            self.k1.data_ptr() + o4, self.k2.data_ptr() + o4, 0, s())
+            else:
+                nv.call('bpb_masked_pool', x.data_ptr(), self.dlogit.data_ptr(), self.pool_part.data_ptr(), n, HW, Cc, K1, None, s())
+                nv.call('bpb_head_bwd_params', self.pool_part.data_ptr(), n * self.nchunks, self.lpart.data_ptr(), self.nlpart, n, HW, K1,
+                        Cc, Cc, pc.classifier.weight.data_ptr(), pc.bn.weight.data_ptr(), pc.bn.bias.data_ptr(), self.pix_mean.data_ptr(),
+                        self.pix_invstd.data_ptr(), pc.classifier.weight.grad.data_ptr(), pc.classifier.bias.grad.data_ptr(),
+                        pc.bn.weight.grad.data_ptr(), pc.bn.bias.grad.data_ptr(), self.k1.data_ptr(), self.k2.data_ptr(), 0, s())
             self.touched.update(id(t) for t in (pc.classifier.weight, pc.classifier.bias, pc.bn.weight, pc.bn.bias))
         # non-learnable attention: the masks do not depend on the features; dlogit, k1, k2 and the saved invstd stay zero, so
         # the classifier term of the dx kernel vanishes and only the pooling term remains
-        nv.call('bpb_head_bwd_dx', x.data_ptr(), gpool.data_ptr(), self.pm.data_ptr(), self.zinv.data_ptr(),
-                self.dlogit.data_ptr(), pc.classifier.weight.data_ptr(), pc.bn.weight.data_ptr(), self.pix_mean.data_ptr(),
-                self.pix_invstd.data_ptr(), self.k1.data_ptr(), self.k2.data_ptr(), self.feats.grad.data_ptr(), n, HW, Cc, K1,
-                0, s())
+        first = 0                    # first launch of the backward plan to run
+        if low:
+            # dx_b = U_b^T dM: the pooling coefficients and dlogit go down to the branch resolutions, the gradient is written
+            # straight into the branch outputs' gradients -- the up-sampling backward (launch 0 of the plan) has nothing to do
+            # (the masks resampled to the branches are still there from the forward pass: their normalisation rides in the kernel)
+            nv.call('bpb_lowres_dx', lr.dev.data_ptr(), lr.host, lr.nb, n, J, K1, Cc, HW, gpool.data_ptr(), lr.d_pmb.data_ptr(),
+                    self.zinv.data_ptr(), lr.d_dld.data_ptr() if self.learnable else None, pc.classifier.weight.data_ptr(),
+                    pc.bn.weight.data_ptr(), self.pix_mean.data_ptr(), self.pix_invstd.data_ptr(), self.k1.data_ptr(),
+                    self.k2.data_ptr(), s())
+            first = 1
+        else:
+            nv.call('bpb_head_bwd_dx', x.data_ptr(), gpool.data_ptr(), self.pm.data_ptr(), self.zinv.data_ptr(),
+                    self.dlogit.data_ptr(), pc.classifier.weight.data_ptr(), pc.bn.weight.data_ptr(), self.pix_mean.data_ptr(),
+                    self.pix_invstd.data_ptr(), self.k1.data_ptr(), self.k2.data_ptr(), self.feats.grad.data_ptr(), n, HW, Cc, K1,
+                    0, s())
         hook = getattr(m, '_bucket_hook', None)
         if hook is None:
-            net.run(net.plan_bwd)
+            net.run(net.plan_bwd, first)
         else:
             # data parallel: the all-reduce of a gradient bucket starts as soon as the last launch that writes into it has been
             # enqueued, and runs on RCCL's stream under the remaining backward launches (the arena ends with the head's
             # parameters, whose gradients are complete here; the backbone's become ready from stage 4 down to the stem)
-            pos = 0
+            pos = first
             for idx, buckets in self.bucket_schedule(hook.buckets, m._arena['grad']):
-                if idx >= 0:
+                if idx >= 0 and idx + 1 > pos:
                     net.run(net.plan_bwd, pos, idx + 1)
                     pos = idx + 1
                 hook.ready(buckets, early=idx + 1 < net.plan_bwd[1])
@@ -775,7 +929,7 @@ class _ModelFn(torch.autograd.Function):
         ctx.plan = plan
         ctx.training = training
         ctx.generation = plan.generation
-        ctx.mark_non_differentiable(outs[-3])                  # spatial features
+        ctx.mark_non_differentiable(outs[-3])                  # spatial features (an empty placeholder when not materialised)
         if not plan.learnable:
             ctx.mark_non_differentiable(outs[-4])              # no pixel classifier output
         if plan.binary or not plan.learnable or not training:

@@ -38,6 +38,11 @@ class ConvS1Prob(C.Structure):
                                 'magic_ta')] + [(n, C.c_int) for n in ('S', 'Hi', 'Wi', 'xr')]
 
 
+class HeadBranch(C.Structure):
+    _fields_ = [('x', c_fp), ('dx', c_fp), ('gh', c_fp), ('gw', c_fp), ('w1h', c_fp), ('w1w', c_fp), ('Hs', C.c_int), ('Ws', C.c_int),
+                ('Cs', C.c_int), ('c0', C.c_int), ('sh', C.c_float), ('sw', C.c_float), ('accumulate', C.c_int), ('pad_', C.c_int)]
+
+
 class BnFinalizeArgs(C.Structure):
     _fields_ = [('gamma', c_fp), ('beta', c_fp), ('scale', c_fp), ('shift', c_fp), ('mean', c_fp), ('invstd', c_fp),
                 ('running_mean', c_fp), ('running_var', c_fp), ('counter', c_fp), ('count', C.c_double), ('eps', C.c_float),
@@ -222,10 +227,10 @@ PROTOS = {
     'bpb_maxpool3x3s2_fwd': 'pppiiiip', 'bpb_maxpool3x3s2_bwd': 'pppiiiiip',
     'bpb_bilinear_concat_fwd': 'pp', 'bpb_bilinear_concat_bwd': 'ppp', 'bpb_bilinear_concat_multi_fwd': 'ppipipp',
     'bpb_bilinear_concat_multi_bwd': 'ppip',
-    'bpb_pixel_dots': 'pplppiiiip', 'bpb_masked_pool': 'pppiiiipp', 'bpb_fold_bn': 'ppppppiip',
-    'bpb_softmax_masks': 'ppppppiiip', 'bpb_visibility': 'ppppiiiipp', 'bpb_pool_finalize': 'ppppiiiiiip',
+    'bpb_pixel_dots': 'ppllppiiiip', 'bpb_masked_pool': 'pppiiiipp', 'bpb_fold_bn': 'ppppppiip',
+    'bpb_softmax_masks': 'ppppppiiip', 'bpb_visibility': 'ppppiiiipp', 'bpb_pool_finalize': 'ppppiiiiiiiip',
     'bpb_rowdot': 'pppiip', 'bpb_resize_masks': 'ppiiiiiip', 'bpb_attention_from_masks': 'pppppiiiiip', 'bpb_head_bwd_dlogits': 'pppppppppiiipppp',
-    'bpb_head_bwd_params': 'pipiiiiipppppppppppip', 'bpb_head_bwd_dx': 'ppppppppppppiiiiip',
+    'bpb_head_bwd_params': 'pipiiiiiipppppppppppip', 'bpb_head_bwd_dx': 'ppppppppppppiiiiip',
     'bpb_gemm': 'pllpllplpiiiippp', 'bpb_gemm_grouped': 'piplpp', 'bpb_colsum': 'ppiiip',
     'bpb_bn1d_fwd': 'plpliippppppffiip', 'bpb_bn1d_bwd': 'plplplpliipppppiip',
     'bpb_ce_label_smooth': 'plpipiiifppplpp', 'bpb_pixel_ce': 'pppiiiiiifppipp',
@@ -235,6 +240,8 @@ PROTOS = {
     'bpb_mask_preprocess': 'pppiiiiiiiiiffpp', 'bpb_bn_eval_affine_batched': 'piifp',
     'bpb_eval_rank': 'pppppiiiipppp', 'bpb_re_ranking': 'pppiiiifip', 'bpb_re_ranking_gpu_workspace': 'iiiipp',
     'bpb_re_ranking_gpu': 'pppiiiifpppp', 'bpb_eval_rank_gpu': 'pppppiiippppp',
+    'bpb_lowres_stats_rows': 'piip', 'bpb_lowres_stats': 'ppiiipp', 'bpb_lowres_upsample_sum': 'ppipppiiiip',
+    'bpb_lowres_adjoint': 'ppipppiiiip', 'bpb_lowres_dx': 'ppiiiiii' + 'p' * 11,
 }
 
 EXPORTS = [
@@ -248,4 +255,5 @@ EXPORTS = [
     'bpb_fill', 'bpb_plan_run', 'bpb_plan_run_timed', 'bpb_part_distance', 'bpb_part_distance_fill', 'bpb_l2_normalize_rows', 'bpb_eval_rank',
     'bpb_mask_preprocess', 'bpb_re_ranking', 'bpb_re_ranking_gpu', 'bpb_re_ranking_gpu_workspace', 'bpb_eval_rank_gpu', 'bpb_bn_eval_affine_batched', 'bpb_resize_masks', 'bpb_attention_from_masks', 'bpb_conv_s1_init', 'bpb_conv_s1', 'bpb_wgrad16_init', 'bpb_conv_wgrad16', 'bpb_wgrad1x1_init', 'bpb_conv_wgrad1x1', 'bpb_fuse_fwd_multi', 'bpb_term_bwd_multi', 'bpb_bn_finalize_multi',
     'bpb_bn_bwd_finalize_multi', 'bpb_wgrad_reduce_multi',
+    'bpb_lowres_stats_rows', 'bpb_lowres_stats', 'bpb_lowres_upsample_sum', 'bpb_lowres_adjoint', 'bpb_lowres_dx',
 ]

@@ -400,8 +400,10 @@ int bpb_bilinear_concat_multi_bwd(const BpbBilinearBwdDesc* d_descs, const BpbBi
 /* ---- body-part attention head -----------------------------------------------------------------------------------
  * torchreid/models/bpbreid.py:147-148 (PixelToPartClassifier :376-385 + softmax), :157-158,178 (bg/parts/fg masks),
  * :182-192 (visibility scores), :195 (global average pool), :198-202 with :458-468 (GAP heads) and :490-503 (GWAP head). */
-int bpb_pixel_dots(const float* x, const float* w, long w_image_stride, const float* bias, float* out, int N, int HW, int C,
-                   int J, hipStream_t stream);
+/* out[n][p][j] = sum_c w[n * w_image_stride + j * w_row_stride + c] x[n][p][c] + bias[j]  (w_row_stride = C for a dense [J][C]
+ * matrix; a column block of a wider matrix otherwise: the per-branch slices of the low-resolution head) */
+int bpb_pixel_dots(const float* x, const float* w, long w_image_stride, long w_row_stride, const float* bias, float* out, int N,
+                   int HW, int C, int J, hipStream_t stream);
 int bpb_masked_pool(const float* x, const float* m, float* part, int N, int HW, int C, int J, int* nchunks_out,
                     hipStream_t stream);
 int bpb_fold_bn(const float* w, const float* b, const float* scale, const float* shift, float* wf, float* bf, int K1, int C,
@@ -421,18 +423,53 @@ int bpb_visibility(const float* probs, const unsigned char* argcls, float* vis, 
 /* parts_gap != 0: the part rows (j >= 3) are normalised by 1/HW like the fg / bg rows -- pooling = 'gap'
  * (GlobalAveragePoolingHead, bpbreid.py:432-441, :485-486) instead of 'gwap' (bpbreid.py:490-503) */
 int bpb_pool_finalize(const float* part, const float* pm, float* pooled, float* zinv, int N, int nchunks, int J, int HW,
-                      int C, int parts_gap, hipStream_t stream);
+                      int C, int parts_gap, int c0, int Ct, hipStream_t stream);
+/* (`part` holds the channels [c0, c0 + C) of the Ct pooled channels: c0 = 0, Ct = C for a materialised map) */
 int bpb_rowdot(const float* a, const float* b, float* out, int rows, int C, hipStream_t stream);
 int bpb_head_bwd_dlogits(const float* D, const float* probs, const unsigned char* argpart, const float* zinv,
                          const float* gp, const float* dlogit_ext, float* dlogit, double* lpart, int* nblocks_out, int N,
                          int HW, int K1, const float* dvis, const float* dfg, const int* argpix, hipStream_t stream);
 /* dvis [N][K1], dfg [N] (optional): gradients of the continuous visibility / foreground-visibility scores; argpix from bpb_visibility */
-int bpb_head_bwd_params(const float* part, int nparts, const double* lpart, int nlpart, int N, int HW, int K1, int C, const float* W,
-                        const float* gamma, const float* beta, const float* mean, const float* invstd, float* dW,
+/* ldw: row stride of W / dW ([K1][ldw], ldw = C for the whole map; the per-channel vectors are offset by the caller) */
+int bpb_head_bwd_params(const float* part, int nparts, const double* lpart, int nlpart, int N, int HW, int K1, int C, int ldw,
+                        const float* W, const float* gamma, const float* beta, const float* mean, const float* invstd, float* dW,
                         float* dbias, float* dgamma, float* dbeta, float* k1, float* k2, int accumulate, hipStream_t stream);
 int bpb_head_bwd_dx(const float* x, const float* G, const float* pm, const float* zinv, const float* dlogit, const float* W,
                     const float* gamma, const float* mean, const float* invstd, const float* k1, const float* k2, float* dx,
                     int N, int HW, int C, int K1, int accumulate, hipStream_t stream);
+
+/* ---- the same head WITHOUT the concatenated map (csrc/head_lowres.hip) ----------------------------------------------------
+ * torchreid/models/hrnet.py:568-573 up-samples the branch outputs bilinearly and concatenates them (1 GB at batch 64);
+ * bpbreid.py:147-148, :195-202, :376-385, :458-503 then only apply operations that are linear along the pixel axis, so the
+ * channel reductions run on the branch outputs and only K+1 logit channels / the K+3 masks are resampled. */
+typedef struct BpbHeadBranch {
+    const float* x;         // [N][Hs][Ws][Cs] branch output (NHWC)
+    float* dx;              // its gradient (bpb_lowres_dx)
+    const float* gh;        // [Hs][3]: bands (i-1, i, i+1) of U_h^T U_h, U_h = the [H][Hs] bilinear align_corners matrix
+    const float* gw;        // [Ws][3]
+    const float* w1h;       // [Hs]: column sums of U_h
+    const float* w1w;       // [Ws]
+    int Hs, Ws, Cs, c0;     // resolution, channels, first channel inside the concatenated map
+    float sh, sw;           // (Hs - 1) / (H - 1), (Ws - 1) / (W - 1) in fp32 (ATen's align_corners scale)
+    int accumulate;         // bpb_lowres_dx: dx += ...
+    int pad_;
+} BpbHeadBranch;
+/* per-channel (sum, sum of squares) of the virtual map for the pixel classifier's BatchNorm2d (bpbreid.py:379):
+ * partials [bpb_lowres_stats_rows()][2][Ct] doubles, consumed by bpb_bn_finalize */
+int bpb_lowres_stats_rows(const BpbHeadBranch* h_br, int nb, int N, int* rows_out);
+int bpb_lowres_stats(const BpbHeadBranch* d_br, const BpbHeadBranch* h_br, int nb, int N, int Ct, double* partials, hipStream_t stream);
+/* out[n][p][j] = bias[j] + sum_b bilinear_b(lb_b[n][.][j])(p); d_lb: device array of nb pointers to [N][Hs*Ws][J] */
+int bpb_lowres_upsample_sum(const BpbHeadBranch* d_br, const BpbHeadBranch* h_br, int nb, const float* const* d_lb, const float* bias,
+                            float* out, int N, int H, int W, int J, hipStream_t stream);
+/* outs_b[n][j][q] = scale * sum_p U_b[p][q] a[n][j][p] (a: [N][J][H*W]); zinv != NULL: scale = the pooling normalisation of
+ * row j (1/HW for j < 3, |zinv[n][j]| for the part rows), else 1 */
+int bpb_lowres_adjoint(const BpbHeadBranch* d_br, const BpbHeadBranch* h_br, int nb, const float* a, const float* zinv,
+                       float* const* d_outs, int N, int J, int H, int W, hipStream_t stream);
+/* gradient into the branch outputs = U_b^T of the map gradient of bpb_head_bwd_dx.  d_pmb: the pooling masks resampled to the
+ * branches (bpb_lowres_adjoint of the forward pass), zinv [N][J] their normalisation; d_dld == NULL: pooling term only */
+int bpb_lowres_dx(const BpbHeadBranch* d_br, const BpbHeadBranch* h_br, int nb, int N, int J, int K1, int Ct, int HW, const float* G,
+                  const float* const* d_pmb, const float* zinv, const float* const* d_dld, const float* Wc, const float* gamma,
+                  const float* mean, const float* invstd, const float* k1, const float* k2, hipStream_t stream);
 
 /* ---- dense layers after pooling ------------------------------------------------------------------------------------
  * bpbreid.py:324-350 (AfterPoolingDimReduceLayer: Linear + BatchNorm1d + ReLU), :398-415 (BNClassifier), :261-279. */

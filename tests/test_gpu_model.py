@@ -97,7 +97,8 @@ def check_outputs(z, tag32, tag64, out, c=4.0, rel=1e-4, rel_bn=None):
         close(Cm.to_np(pix), z[tag32 + '/pix'], z[tag64 + '/pix'], what='pix', **kw)
     else:
         assert pix is None
-    close(Cm.to_np(Cm.subsample(sp.contiguous())), z[tag32 + '/sp_sub'], z[tag64 + '/sp_sub'], what='spatial', **kw)
+    if sp is not None:       # (None: the model was told not to materialise the concatenated map -- head on the branch outputs)
+        close(Cm.to_np(Cm.subsample(sp.contiguous())), z[tag32 + '/sp_sub'], z[tag64 + '/sp_sub'], what='spatial', **kw)
     close(Cm.to_np(mk['parts']), z[tag32 + '/mask_parts'], z[tag64 + '/mask_parts'], what='masks', **kw)
     close(Cm.to_np(mk['foreg']), z[tag32 + '/mask_foreg'], z[tag64 + '/mask_foreg'], what='fg mask', **kw)
     ref_bg = z[tag32 + '/mask_backg']
@@ -129,8 +130,13 @@ def check_ranking(dm, z):
     return exact
 
 
-@pytest.mark.parametrize('name', list(MODEL_CASES))
-def test_model_matches_reference_golden(name, golden_dir):
+# every HRNet fixture whose head reads the concatenated map directly (no 1x1 dimension reduction in front of it) is also run with
+# the head on the branch outputs (model.materialize_spatial_features = False, csrc/head_lowres.hip): same goldens, same bounds
+LOWRES_CASES = [nm for nm, (bb, ex) in MODEL_CASES.items() if bb.startswith('hrnet') and 'before' not in ex.get('dim_reduce', '')]
+
+
+@pytest.mark.parametrize('name,lowres', [(nm, False) for nm in MODEL_CASES] + [(nm, True) for nm in LOWRES_CASES])
+def test_model_matches_reference_golden(name, lowres, golden_dir):
     path = os.path.join(golden_dir, 'model_%s.npz' % name)
     if not os.path.exists(path):
         pytest.skip('fixture not generated')
@@ -139,13 +145,16 @@ def test_model_matches_reference_golden(name, golden_dir):
     k, d, n, h, w, ncls = [int(x) for x in z['meta']]
     cfg = Cm.make_cfg(backbone, k, d, **extra)
     model = Cm.fill_state_dict_(bpbreid(ncls, config=cfg, pretrained=False)).to(DEV)
+    model.materialize_spatial_features = not lowres
     imgs, masks, pids = Cm.synth_batch(n, h, w, k, ncls)
     imgs, masks, pids = imgs.to(DEV), masks.to(DEV), pids.to(DEV)
     eng = ImagePartBasedEngine(model, optimizer=FusedAdam(model), losses_weights=WEIGHTS_MARKET, mask_filtering_training=True)
     tol = dict(c=4.0, rel=1e-4) if name in TIGHT else dict(c=12.0, rel=3e-4)
     tol_out = tol if name in TIGHT else dict(tol, rel_bn=2e-3)
     model.train()
+    model.materialize_spatial_features = not lowres       # (the engine switches the map off: restore this test's choice)
     out = model(imgs, external_parts_masks=masks)
+    assert (out[4] is None) == lowres
     check_outputs(z, 'f32/train', 'f64/train', out, **tol_out)
     loss, summ = eng.combine_losses(out[1], out[0], out[2], pids, out[3], masks, bpa_weight=0.35)
     close(float(loss.detach()), z['f32/loss_market_vis'], z['f64/loss_market_vis'], what='loss', **tol)
@@ -198,7 +207,7 @@ def test_model_matches_reference_golden(name, golden_dir):
     rr = np.array(ratios)
     rms_err, rms_noise = np.sqrt((rr[:, 0] ** 2).mean()), np.sqrt((rr[:, 1] ** 2).mean())
     os.makedirs('gpurun_out', exist_ok=True)
-    with open('gpurun_out/grad_parity_%s.txt' % name, 'w') as fh:
+    with open('gpurun_out/grad_parity_%s%s.txt' % (name, '_lowres' if lowres else ''), 'w') as fh:
         fh.write('# %d parameters, %d outside max(4*noise, 1e-3*scale), %d outside max(20*noise, 1e-2*scale); rms err/scale '
                  '%.3e vs reference fp32 noise/scale %.3e (x%.2f); median err/noise x%.2f; cosine %.7f (reference fp32 vs fp64: %.7f)\n'
                  % (len(digests), len(loose), len(bad), rms_err, rms_noise, rms_err / max(rms_noise, 1e-30),
@@ -366,10 +375,12 @@ def test_fused_adam_state_interchanges_with_torch_adam(tmp_path):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), n
 
 
-def test_repeated_steps_are_bit_identical_and_grouping_or_kernel_choice_do_not_change_the_result():
+@pytest.mark.parametrize('lowres', [False, True])
+def test_repeated_steps_are_bit_identical_and_grouping_or_kernel_choice_do_not_change_the_result(lowres):
     """No atomics anywhere: the same batch must give bit-identical outputs and gradients on every repetition.  The grouped
     launches are a pure re-packing of the same kernels (bit-identical to one launch per record), and the lean stride-1 conv
-    kernel agrees with the general implicit-GEMM kernel up to fp32 summation order."""
+    kernel agrees with the general implicit-GEMM kernel up to fp32 summation order.  Both head forms: the materialised map and
+    the head on the branch outputs (lowres: the second compared tensor is the pixel-classifier output instead of the map)."""
     cfg = Cm.make_cfg('hrnet_w8', 3, 32)
     imgs, masks, pids = Cm.synth_batch(8, 128, 64, 3, 8)
     imgs, masks, pids = imgs.to(DEV), masks.to(DEV), pids.to(DEV)
@@ -379,15 +390,16 @@ def test_repeated_steps_are_bit_identical_and_grouping_or_kernel_choice_do_not_c
         os.environ.update(env)
         try:
             model = Cm.fill_state_dict_(bpbreid(8, config=cfg, pretrained=False)).to(DEV)
-            eng = ImagePartBasedEngine(model, optimizer=FusedAdam(model), losses_weights=WEIGHTS_DEFAULT)
+            eng = ImagePartBasedEngine(model, optimizer=FusedAdam(model), losses_weights=WEIGHTS_DEFAULT, need_spatial_features=not lowres)
             model.train()
             res = []
             for _ in range(reps):
                 out = model(imgs, external_parts_masks=masks)
+                assert (out[4] is None) == lowres
                 loss, _ = eng.combine_losses(out[1], out[0], out[2], pids, out[3], masks, bpa_weight=0.35)
                 loss.backward()
                 torch.cuda.synchronize()
-                res.append((out[0]['bn_foreg'].clone(), out[4].clone(), model.arena()['grad'].clone(), float(loss)))
+                res.append((out[0]['bn_foreg'].clone(), (out[3] if lowres else out[4]).clone(), model.arena()['grad'].clone(), float(loss)))
             plan = next(iter(model._plans.values()))
             return res, plan.net
         finally:

@@ -14,6 +14,9 @@ backbone = sys.argv[1] if len(sys.argv) > 1 else 'hrnet32'
 k, h, w, n = [int(a) for a in (sys.argv[2:6] if len(sys.argv) > 5 else (5, 256, 128, 64))]
 dev = torch.device('cuda', 0)
 model = Cm.fill_state_dict_(bpbreid(751, config=Cm.make_cfg(backbone, k, 512), pretrained=False)).to(dev)
+# the engine's setting (engine.py): `spatial_features` is not consumed, the head runs on the branch outputs.  BPB_FWD_SPATIAL=1
+# measures the forward that also returns the concatenated 1 GB map.
+model.materialize_spatial_features = os.environ.get('BPB_FWD_SPATIAL', '0') == '1'
 imgs, masks, _ = Cm.synth_batch(n, h, w, k, 751)
 imgs, masks = imgs.to(dev), masks.to(dev)
 res = {}
@@ -35,4 +38,4 @@ for mode in os.environ.get('BPB_FWD_MODES', 'eval,train').split(','):
     flops = sum(m['flops'] for m in (plan.net.plan_eval if mode == 'eval' else plan.net.plan_train)[2])
     res[mode] = {'ms_per_batch': ms, 'images_per_s': n / ms * 1e3, 'conv_tflops': flops / ms * 1e-9,
                  'frac_of_f32_mfma_peak': flops / ms * 1e-9 / 157.3}
-print(json.dumps({'backbone': backbone, 'batch': n, 'forward_only': res}))
+print(json.dumps({'backbone': backbone, 'batch': n, 'spatial_features_materialised': model.materialize_spatial_features, 'forward_only': res}))
