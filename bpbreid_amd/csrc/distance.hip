@@ -112,19 +112,27 @@ __global__ __launch_bounds__(256) void bpb_part_distance_kernel(const float* __r
 // (four 32x32 accumulators each), 32-wide K chunks streamed global -> LDS by `buffer_load ... lds` DMA into a double buffer
 // (one barrier per chunk, out-of-range rows zero-filled by the descriptor), operands read as 16-byte fragments with the
 // same channel permutation as the convolution kernel ([row][8 data + 1 pad slots]: conflict-free).  Each part's distance
-// is folded into ONE register array (masked sum or masked max); the pair weights sum_p m_p are recomputed from the
-// visibility vectors at the end instead of being carried through the P loop.  Arithmetic per element is identical to the
-// 64x64 kernel above (same fp32 operation order) -- the MFMA k-order differs (8-channel groups), which is round-off only.
+// is folded into ONE register array (masked sum or masked max).  Arithmetic per element is identical to the 64x64 kernel
+// above (same fp32 operation order) -- the MFMA k-order differs (8-channel groups), which is round-off only.
+//
+// Round 3 (profiles/r03_pmc_sq_distance.txt: 6.1 VALU and 0.5 VMEM instructions per MFMA, one workgroup per CU, 0.33 of the
+// peak): the per-part epilogue no longer does 64-bit index arithmetic and 128 scattered loads per lane -- the query-side norms
+// of the tile are staged in LDS once per part, the visibility of boolean masks is ONE bit mask per row (pair mask = a bit test,
+// number of shared parts = a population count), stores address a per-part base pointer with 32-bit lane offsets -- and the
+// staging regions are packed (no piece padding) so that two workgroups share a CU.
+// Workgroup = 8 waves (512 threads): wave (wq, wg) owns the 32 query rows wq x 64 gallery columns wg of the 128 x 128 tile --
+// 64 accumulator + 64 combination registers per lane would not leave room for two workgroups per CU with four 64 x 64 waves.
 template <int STRAT>
-__global__ __launch_bounds__(256) void bpb_part_distance_tiled_kernel(const float* __restrict__ qf, const float* __restrict__ gf,
-                                                                        const float* __restrict__ qsq, const float* __restrict__ gsq,
-                                                                        const float* __restrict__ qvis, const float* __restrict__ gvis,
-                                                                        int Q, int G, int P, int D, int mode, int cosine,
-                                                                        float* __restrict__ parts_out, float* __restrict__ dist_out,
-                                                                        int* __restrict__ maxbits, unsigned q_bytes, unsigned g_bytes)
+__global__ __launch_bounds__(512, 2) void bpb_part_distance_tiled_kernel(const float* __restrict__ qf, const float* __restrict__ gf,
+                                                                           const float* __restrict__ qsq, const float* __restrict__ gsq,
+                                                                           const float* __restrict__ qvis, const float* __restrict__ gvis,
+                                                                           int Q, int G, int P, int D, int mode, int cosine,
+                                                                           float* __restrict__ parts_out, float* __restrict__ dist_out,
+                                                                           int* __restrict__ maxbits, unsigned q_bytes, unsigned g_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int SLOTS = 1280;                       // 128 rows x 9 slots = 1152, padded to 5 x 256 DMA pieces
+    constexpr int SLOTS = 1152;                       // 128 rows x 9 slots = 2.25 DMA pieces of 512 lanes (the third: waves 0, 1)
+    constexpr int BUF = 2 * SLOTS * 16;               // bytes of one {A, B} buffer
     constexpr unsigned OOB = 0x80000000u;
     const int tiles_g = (G + 127) >> 7;
     const int tq = blockIdx.x / tiles_g, tg = blockIdx.x % tiles_g;
@@ -134,43 +142,61 @@ __global__ __launch_bounds__(256) void bpb_part_distance_tiled_kernel(const floa
     const int wq = wave >> 1, wg = wave & 1;
     const int q0 = tq * 128, g0 = tg * 128;
     const long PD = (long)P * D;
+    float* sq_s = (float*)((char*)smem + 2 * BUF);               // [128] squared norms of the tile's query rows, current part
+    unsigned* qb_s = (unsigned*)((char*)smem + 2 * BUF + 512);  // [128] visibility bit mask of the tile's query rows (mode 1)
 
     __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)qf, 0, (int)q_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)gf, 0, (int)g_bytes, 0x00020000);
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    unsigned aofs[5], bofs[5];
+    unsigned aofs[3], bofs[3];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const int idx = k * 256 + (int)threadIdx.x;
+    for (int k = 0; k < 3; ++k) {
+        const int idx = k * 512 + (int)threadIdx.x;
         const int row = idx / 9, v = idx - row * 9;
-        const bool ok = idx < 1152 && v < 8;
+        const bool ok = idx < SLOTS && v < 8;
         aofs[k] = (ok && q0 + row < Q) ? (unsigned)(((long)(q0 + row) * PD + v * 4) * 4) : OOB;
         bofs[k] = (ok && g0 + row < G) ? (unsigned)(((long)(g0 + row) * PD + v * 4) * 4) : OOB;
     }
     auto dma_issue = [&](int p, int k0, int buf) {
-        const unsigned inc = (unsigned)((p * D + k0) * 4);
-        char* base = (char*)smem + buf * (2 * SLOTS * 16) + wave * 1024;
+        const int inc = (p * D + k0) * 4;             // rides in the instruction's scalar offset: the lane offsets are loop invariants
+        char* base = (char*)smem + buf * BUF + wave * 1024;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_ptr_t)(base + k * 4096), 16, (int)(aofs[k] + inc), 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_ptr_t)(base + SLOTS * 16 + k * 4096), 16, (int)(bofs[k] + inc), 0, 0, 0);
+        for (int k = 0; k < 3; ++k) {
+            if (k == 2 && wave >= 2) continue;        // the third piece holds 128 slots: only waves 0, 1 have lanes in it
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_ptr_t)(base + k * 8192), 16, (int)aofs[k], inc, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_ptr_t)(base + SLOTS * 16 + k * 8192), 16, (int)bofs[k], inc, 0, 0);
         }
     };
-    const int a_lane = ((wq * 64 + l31) * 9 + half) * 16;          // byte offset of this lane's A fragment (mt = 0, kg = 0)
+    const int a_lane = ((wq * 32 + l31) * 9 + half) * 16;          // byte offset of this lane's A fragment (kg = 0)
     const int b_lane = SLOTS * 16 + ((wg * 64 + l31) * 9 + half) * 16;
 
-    f32x16 comb[2][2];
+    // this lane's two gallery columns and the visibility bit masks (boolean visibility: the pair mask of part p is bit p of
+    // qbits & gbits, the number of shared visible parts its population count)
+    int gcol[2];
+    unsigned gbits[2] = {0u, 0u};
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int nt = 0; nt < 2; ++nt) {
+        gcol[nt] = g0 + wg * 64 + nt * 32 + l31;
+        if (mode == 1 && gcol[nt] < G)
+            for (int pp = 0; pp < P; ++pp) gbits[nt] |= (gvis[(long)gcol[nt] * P + pp] != 0.f ? 1u : 0u) << pp;
+    }
+    if (mode == 1 && threadIdx.x < 128) {
+        unsigned b = 0u;
+        if (q0 + (int)threadIdx.x < Q)
+            for (int pp = 0; pp < P; ++pp) b |= (qvis[(long)(q0 + threadIdx.x) * P + pp] != 0.f ? 1u : 0u) << pp;
+        qb_s[threadIdx.x] = b;
+    }
+
+    f32x16 comb[2];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) comb[mt][nt][r] = STRAT == 1 ? -1.f : 0.f;
+        for (int r = 0; r < 16; ++r) comb[nt][r] = STRAT == 1 ? -1.f : 0.f;
     float lmax = 0.f;
     const int nch = D >> 5;
     const int nwork = P * nch;
     dma_issue(0, 0, 0);
-    f32x16 acc[2][2];
+    f32x16 acc[2];
     int p = 0, ch = 0;
     for (int w = 0; w < nwork; ++w) {
         __syncthreads();                                   // chunk w has landed; the other buffer is free
@@ -180,28 +206,24 @@ __global__ __launch_bounds__(256) void bpb_part_distance_tiled_kernel(const floa
         }
         if (ch == 0) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+            // (every wave is past the barrier above, i.e. past the previous part's epilogue: the staged norms may be replaced)
+            if (!cosine && threadIdx.x < 128) sq_s[threadIdx.x] = q0 + (int)threadIdx.x < Q ? qsq[(long)(q0 + threadIdx.x) * P + p] : 0.f;
         }
-        const char* sb = (const char*)smem + (w & 1) * (2 * SLOTS * 16);
-        f32x4 a[2][2], b[2][2];                             // [ping-pong][sub-tile]
-        auto fetch = [&](int kg, f32x4 (&af)[2], f32x4 (&bf)[2]) {
+        const char* sb = (const char*)smem + (w & 1) * BUF;
+        f32x4 a[2], b[2][2];                                // [ping-pong]([sub-tile])
+        auto fetch = [&](int kg, f32x4& af, f32x4 (&bf)[2]) {
+            af = *(const f32x4*)(sb + a_lane + kg * 32);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                af[t] = *(const f32x4*)(sb + a_lane + t * (32 * 9 * 16) + kg * 32);
-                bf[t] = *(const f32x4*)(sb + b_lane + t * (32 * 9 * 16) + kg * 32);
-            }
+            for (int t = 0; t < 2; ++t) bf[t] = *(const f32x4*)(sb + b_lane + t * (32 * 9 * 16) + kg * 32);
         };
-        auto mma = [&](const f32x4 (&af)[2], const f32x4 (&bf)[2]) {
+        auto mma = [&](const f32x4& af, const f32x4 (&bf)[2]) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = MFMA32(af[mt][i], bf[nt][i], acc[mt][nt]);
+                for (int nt = 0; nt < 2; ++nt) acc[nt] = MFMA32(af[i], bf[nt][i], acc[nt]);
         };
         fetch(0, a[0], b[0]);
         fetch(1, a[1], b[1]);
@@ -218,35 +240,44 @@ __global__ __launch_bounds__(256) void bpb_part_distance_tiled_kernel(const floa
         __builtin_amdgcn_sched_barrier(0);
         mma(a[1], b[1]);
         if (++ch == nch) {                                  // ---- this part is complete: distances, mask, fold
+            __syncthreads();                                // the norms staged at the part's first chunk (nch may be 1)
+            // per-part base of the output block of this tile: the lane offsets below stay 32-bit
+            float* pbase = parts_out ? parts_out + ((long)p * Q + q0) * G : nullptr;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                const int g = g0 + wg * 64 + nt * 32 + l31;
+                const int g = gcol[nt];
                 const bool gok = g < G;
-                const float gs = gok ? gsq[(long)g * P + p] : 0.f;
-                const float gv = (mode != 0 && gok) ? gvis[(long)g * P + p] : 1.f;
+                const float gs = (gok && !cosine) ? gsq[(long)g * P + p] : 0.f;
+                const float gv = (mode == 2 && gok) ? gvis[(long)g * P + p] : 1.f;
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
+                for (int rq4 = 0; rq4 < 4; ++rq4) {
+                    const int rowb = wq * 32 + 8 * rq4 + 4 * half;                 // four consecutive query rows of the tile
+                    const f32x4 qs4 = cosine ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(sq_s + rowb);
+                    unsigned qb4[4] = {0u, 0u, 0u, 0u};
+                    if (mode == 1) {
+                        const uint4 t4 = *(const uint4*)(qb_s + rowb);
+                        qb4[0] = t4.x; qb4[1] = t4.y; qb4[2] = t4.z; qb4[3] = t4.w;
+                    }
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int q = q0 + wq * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        if (q < Q && gok) {
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int r = rq4 * 4 + jj;
+                        const int row = rowb + jj;
+                        if (q0 + row < Q && gok) {
                             float d;
-                            if (cosine) d = 1.f - acc[mt][nt][r];
+                            if (cosine) d = 1.f - acc[nt][r];
                             else {
-                                d = qsq[(long)q * P + p] - 2.f * acc[mt][nt][r] + gs;
+                                d = qs4[jj] - 2.f * acc[nt][r] + gs;
                                 d = sqrtf(d > 0.f ? d : 0.f);
                             }
                             float m = 1.f;
-                            if (mode != 0) {
-                                m = qvis[(long)q * P + p] * gv;
-                                if (mode == 2) m = sqrtf(m);
-                            }
+                            if (mode == 1) m = ((qb4[jj] & gbits[nt]) >> p) & 1u ? 1.f : 0.f;
+                            else if (mode == 2) m = sqrtf(qvis[(long)(q0 + row) * P + p] * gv);
                             float pv = d;
                             if (mode == 1 && m == 0.f) pv = -1.f;
-                            if (parts_out) parts_out[((long)p * Q + q) * G + g] = pv;
+                            if (pbase) pbase[(unsigned)row * (unsigned)G + (unsigned)g] = pv;
                             if (pv > lmax) lmax = pv;
-                            if (STRAT == 1) { if (m != 0.f && d > comb[mt][nt][r]) comb[mt][nt][r] = d; }
-                            else comb[mt][nt][r] += d * m;
+                            if (STRAT == 1) { if (m != 0.f && d > comb[nt][r]) comb[nt][r] = d; }
+                            else comb[nt][r] += d * m;
                         }
                     }
                 }
@@ -257,27 +288,23 @@ __global__ __launch_bounds__(256) void bpb_part_distance_tiled_kernel(const floa
     }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-        const int g = g0 + wg * 64 + nt * 32 + l31;
+        const int g = gcol[nt];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int q = q0 + wq * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (q < Q && g < G) {
-                    float v;
-                    if (STRAT == 1) v = comb[mt][nt][r];                       // stays -1 when no part is shared
-                    else if (mode == 0) v = comb[mt][nt][r] / (float)P;
-                    else {
-                        float sw = 0.f;                                         // sum_p m_p, same order as the P loop
-                        for (int pp = 0; pp < P; ++pp) {
-                            float m = qvis[(long)q * P + pp] * gvis[(long)g * P + pp];
-                            if (mode == 2) m = sqrtf(m);
-                            sw += m;
-                        }
-                        v = sw == 0.f ? -1.f : comb[mt][nt][r] / sw;
-                    }
-                    dist_out[(long)q * G + g] = v;
+        for (int r = 0; r < 16; ++r) {
+            const int row = wq * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int q = q0 + row;
+            if (q < Q && g < G) {
+                float v;
+                if (STRAT == 1) v = comb[nt][r];                               // stays -1 when no part is shared
+                else if (mode == 0) v = comb[nt][r] / (float)P;
+                else {
+                    float sw = 0.f;                                             // sum_p m_p
+                    if (mode == 1) sw = (float)__popc(qb_s[row] & gbits[nt]);   // (a sum of P zeros and ones: exact in any order)
+                    else
+                        for (int pp = 0; pp < P; ++pp) sw += sqrtf(qvis[(long)q * P + pp] * gvis[(long)g * P + pp]);   // same order as the P loop
+                    v = sw == 0.f ? -1.f : comb[nt][r] / sw;
                 }
+                dist_out[(long)q * G + g] = v;
             }
         }
     }
@@ -330,9 +357,11 @@ int bpb_part_distance(const float* qf, const float* gf, const float* qvis, const
     hipLaunchKernelGGL(bpb_rownorm_kernel, dim3(bpb_cdiv((long)Q * P, 4)), dim3(256), 0, stream, qf, qsq, (long)Q * P, D);
     hipLaunchKernelGGL(bpb_rownorm_kernel, dim3(bpb_cdiv((long)G * P, 4)), dim3(256), 0, stream, gf, gsq, (long)G * P, D);
     const double qb = (double)Q * P * D * 4.0, gb = (double)G * P * D * 4.0;
-    if (D % 32 == 0 && qb < 2147483648.0 && gb < 2147483648.0 && (Q >= 128 || G >= 128)) {
+    // (boolean visibility rides as one 32-bit mask per row in the tiled kernel: P <= 32; a block of 128 rows x G of the per-part
+    // output is addressed with 32-bit lane offsets)
+    if (D % 32 == 0 && qb < 2147483648.0 && gb < 2147483648.0 && (Q >= 128 || G >= 128) && P <= 32 && (double)G * 128.0 * 4.0 < 4294967296.0) {
         static bool attr_done = false;
-        const int lds = 2 * 2 * 1280 * 16;
+        const int lds = 2 * 2 * 1152 * 16 + 1024;          // two {A, B} buffers + the staged query norms / visibility bits
         if (!attr_done) {
             (void)hipFuncSetAttribute((const void*)bpb_part_distance_tiled_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             (void)hipFuncSetAttribute((const void*)bpb_part_distance_tiled_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -340,10 +369,10 @@ int bpb_part_distance(const float* qf, const float* gf, const float* qvis, const
         }
         const int tiles = bpb_cdiv(Q, 128) * bpb_cdiv(G, 128);
         if (strat == 1)
-            hipLaunchKernelGGL(bpb_part_distance_tiled_kernel<1>, dim3(tiles), dim3(256), lds, stream, qf, gf, qsq, gsq, qvis, gvis,
+            hipLaunchKernelGGL(bpb_part_distance_tiled_kernel<1>, dim3(tiles), dim3(512), lds, stream, qf, gf, qsq, gsq, qvis, gvis,
                                Q, G, P, D, mode, cosine, parts_out, dist_out, maxbits, (unsigned)qb, (unsigned)gb);
         else
-            hipLaunchKernelGGL(bpb_part_distance_tiled_kernel<0>, dim3(tiles), dim3(256), lds, stream, qf, gf, qsq, gsq, qvis, gvis,
+            hipLaunchKernelGGL(bpb_part_distance_tiled_kernel<0>, dim3(tiles), dim3(512), lds, stream, qf, gf, qsq, gsq, qvis, gvis,
                                Q, G, P, D, mode, cosine, parts_out, dist_out, maxbits, (unsigned)qb, (unsigned)gb);
     } else {
         const int tiles = bpb_cdiv(Q, 64) * bpb_cdiv(G, 64);
