@@ -491,6 +491,23 @@ __global__ __launch_bounds__(256) void bpb_scale_kernel(const float* __restrict_
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) y[i] = accumulate ? y[i] + a * x[i] : a * x[i];
 }
 
+struct BpbScalarTerms {
+    const float* p[8];
+    float w[8];
+};
+__global__ void bpb_weighted_sum_kernel(BpbScalarTerms t, int n, float* __restrict__ out)
+{
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += t.w[i] * t.p[i][0];
+        out[0] = s;
+    }
+}
+__global__ void bpb_scalar_fanout_kernel(BpbScalarTerms t, int n, const float* __restrict__ gloss, float* __restrict__ out)
+{
+    if ((int)threadIdx.x < n) out[threadIdx.x] = gloss[0] * t.w[threadIdx.x];
+}
+
 extern "C" {
 
 // scratch: row_loss[R], row_ok[R] floats.  out: [loss, accuracy].
@@ -553,6 +570,29 @@ int bpb_part_triplet_bwd(const float* emb, long se_n, long se_k, const float* gs
 {
     hipLaunchKernelGGL(bpb_triplet_bwd_kernel, dim3(N, K), dim3(256), N * 4, stream, emb, se_n, se_k, gsq, gscale, gmul, N, K,
                        D, demb, sd_n, sd_k, accumulate);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+// loss = sum_i w_i * term_i over up to 8 device scalars (GiLt_loss.py:45-76 `loss += weight * term`, part_based_engine.py:126
+// `loss += bpa_weight * bpa_loss`): one launch instead of a multiply per term, a stack and a reduction; fixed order.
+// fan-out (backward): out[i] = gloss * w_i.
+int bpb_weighted_sum(const float* const* h_terms, const float* h_weights, int n, float* out, hipStream_t stream)
+{
+    BPB_REQUIRE(n >= 1 && n <= 8, "bpb_weighted_sum: %d terms (1..8)", n);
+    BpbScalarTerms t;
+    for (int i = 0; i < 8; ++i) { t.p[i] = i < n ? h_terms[i] : nullptr; t.w[i] = i < n ? h_weights[i] : 0.f; }
+    hipLaunchKernelGGL(bpb_weighted_sum_kernel, dim3(1), dim3(64), 0, stream, t, n, out);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_scalar_fanout(const float* gloss, const float* h_weights, int n, float* out, hipStream_t stream)
+{
+    BPB_REQUIRE(n >= 1 && n <= 8, "bpb_scalar_fanout: %d terms (1..8)", n);
+    BpbScalarTerms t;
+    for (int i = 0; i < 8; ++i) { t.p[i] = nullptr; t.w[i] = i < n ? h_weights[i] : 0.f; }
+    hipLaunchKernelGGL(bpb_scalar_fanout_kernel, dim3(1), dim3(64), 0, stream, t, n, gloss, out);
     BPB_LAUNCH_OK();
     return 0;
 }

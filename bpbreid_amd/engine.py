@@ -10,11 +10,13 @@ What is deliberately NOT copied from the reference engine: the three device sync
 timers (utils/avgmeter.py:273), the >=10 `.item()` calls of its meters and the CPU one-hot of its CE loss.
 `loss_summary` holds device scalars; read them when (and if) you want to log.
 """
+import contextlib
+
 import torch
 
 from . import native as nv
 from .distributed import GradAllReducer
-from .losses import GiLtLoss, BodyPartAttentionLoss
+from .losses import GiLtLoss, BodyPartAttentionLoss, weighted_sum
 from .metrics import compute_distance_matrix_using_bp_features, evaluate_rank, part_distance_raw, re_ranking
 from .model import bn_correspondants, PIXELS
 from .optim import FusedAdam
@@ -185,13 +187,17 @@ class ImagePartBasedEngine:
 
     def combine_losses(self, visibility_scores_dict, embeddings_dict, id_cls_scores_dict, pids, pixels_cls_scores=None,
                        target_masks=None, bpa_weight=0):
-        loss, loss_summary = self.GiLt(embeddings_dict, visibility_scores_dict, id_cls_scores_dict, pids)
+        weights, terms, loss_summary = self.GiLt.weighted_terms(embeddings_dict, visibility_scores_dict, id_cls_scores_dict, pids)
         if pixels_cls_scores is not None and target_masks is not None and bpa_weight > 0:
             # the bilinear resize + argmax of the target masks happens inside the pixel-CE kernel
             bpa_loss, bpa_summary = self.body_part_attention_loss(pixels_cls_scores, target_masks)
-            loss = loss + bpa_weight * bpa_loss
+            terms.append(bpa_loss)
+            weights.append(bpa_weight)
             loss_summary = {**loss_summary, **bpa_summary}
-        return loss, loss_summary
+        if not terms:
+            return torch.zeros((), device=pids.device), loss_summary
+        # GiLt's identity / triplet terms and the body-part-attention term in ONE weighted sum (one launch, no torch arithmetic)
+        return weighted_sum(weights, terms), loss_summary
 
     # ------------------------------------------------------------------ evaluation
     def extract_test_embeddings(self, model_output):
@@ -232,14 +238,16 @@ class ImagePartBasedEngine:
             b0, b1 = gallery_shard(len(batches), world, rank)
             batches = batches[b0:b1]
         feats, viss, pids, camids = [], [], [], []
-        for data in batches:
-            imgs = data['image'].to(dev)
-            masks = data['mask'].to(dev) if data.get('mask') is not None else None
-            f, v, _, _ = self.extract_test_embeddings(self.model(imgs, external_parts_masks=masks))
-            feats.append(f.clone())
-            viss.append(v.clone())
-            pids.extend(int(x) for x in data.get('pid', []))
-            camids.extend(int(x) for x in data.get('camid', []))
+        cached = self.model.eval_weights_cached() if hasattr(self.model, 'eval_weights_cached') else contextlib.nullcontext()
+        with cached:       # nothing trains inside this loop: BatchNorm affines / packed eval weights are derived once
+            for data in batches:
+                imgs = data['image'].to(dev)
+                masks = data['mask'].to(dev) if data.get('mask') is not None else None
+                f, v, _, _ = self.extract_test_embeddings(self.model(imgs, external_parts_masks=masks))
+                feats.append(f.clone())
+                viss.append(v.clone())
+                pids.extend(int(x) for x in data.get('pid', []))
+                camids.extend(int(x) for x in data.get('camid', []))
         f = torch.cat(feats) if feats else torch.empty(0, device=dev)
         v = (torch.cat(viss) if viss else torch.empty(0, device=dev)) if self.mask_filtering_testing else None
         if shard and gather and world > 1:

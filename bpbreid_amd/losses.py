@@ -10,6 +10,7 @@ Same class names, constructor and call signatures as the reference so an engine 
 Differences by design: no host synchronisation (no boolean indexing, no .item()), the writer is optional and
 only absorbs calls, and scalar results stay on the device.
 """
+import ctypes as C
 from collections import OrderedDict
 
 import torch
@@ -227,6 +228,39 @@ def init_part_based_triplet_loss(name, **kwargs):
     return __body_parts_losses[name](**kwargs)
 
 
+class _WeightedSumFn(torch.autograd.Function):
+    """loss = sum_i w_i * term_i over device scalars in ONE launch (the reference: `loss += weight * term` per term,
+    GiLt_loss.py:45-76 and part_based_engine.py:126); backward: one launch for the n scalars gloss * w_i."""
+
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        _need_cuda(terms[0], 'GiLtLoss')
+        ts = [t.detach().reshape(1).to(torch.float32) for t in terms]
+        out = torch.empty(1, device=ts[0].device, dtype=torch.float32)
+        ptrs = (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        ws = (C.c_float * len(ts))(*[float(w) for w in weights])
+        nv.call('bpb_weighted_sum', ptrs, ws, len(ts), out.data_ptr(), nv.stream())
+        ctx.weights, ctx.shapes = ws, [t.shape for t in terms]
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, gloss):
+        n = len(ctx.shapes)
+        g = torch.empty(n, device=gloss.device, dtype=torch.float32)
+        gl = gloss.reshape(1).to(torch.float32).contiguous()
+        nv.call('bpb_scalar_fanout', gl.data_ptr(), ctx.weights, n, g.data_ptr(), nv.stream())
+        return (None,) + tuple(g[i].reshape(sh) for i, sh in enumerate(ctx.shapes))
+
+
+def weighted_sum(weights, terms):
+    """sum_i weights[i] * terms[i] (device scalars), chunks of 8 per launch."""
+    terms, weights = list(terms), list(weights)
+    while len(terms) > 8:
+        terms = [_WeightedSumFn.apply(tuple(weights[:8]), *terms[:8])] + terms[8:]
+        weights = [1.0] + weights[8:]
+    return _WeightedSumFn.apply(tuple(weights), *terms)
+
+
 class GiLtLoss(nn.Module):
     """Global-identity Local-triplet loss (GiLt_loss.py:11-119)."""
 
@@ -242,25 +276,33 @@ class GiLtLoss(nn.Module):
         self.use_visibility_scores = use_visibility_scores
 
     def forward(self, embeddings_dict, visibility_scores_dict, id_cls_scores_dict, pids):
-        loss_summary, terms = {}, []
+        weights, terms, loss_summary = self.weighted_terms(embeddings_dict, visibility_scores_dict, id_cls_scores_dict, pids)
+        if not terms:
+            return torch.zeros((), device=pids.device), loss_summary
+        return weighted_sum(weights, terms), loss_summary
+
+    def weighted_terms(self, embeddings_dict, visibility_scores_dict, id_cls_scores_dict, pids):
+        """-> (weights, loss terms, summary): the weighted sum itself is one launch (weighted_sum); the engine appends its
+        body-part-attention term to the same sum (part_based_engine.py:126)."""
+        loss_summary, terms, weights = {}, [], []
         keys = [GLOBAL, FOREGROUND, CONCAT_PARTS, PARTS]
         for key in keys:
             info = OrderedDict()
             w = self.losses_weights[key]['id']
             if w > 0:
                 c, a = self.compute_id_cls_loss(id_cls_scores_dict[key], visibility_scores_dict[key], pids)
-                terms.append(w * c)
+                terms.append(c)
+                weights.append(w)
                 info['c'], info['a'] = c, a
             loss_summary[key] = info
         for key in keys:
             w = self.losses_weights[key]['tr']
             if w > 0:
                 t, tt, vt = self.compute_triplet_loss(embeddings_dict[key], visibility_scores_dict[key], pids)
-                terms.append(w * t)
+                terms.append(t)
+                weights.append(w)
                 loss_summary[key].update(t=t, tt=tt, vt=vt)
-        if not terms:
-            return torch.zeros((), device=pids.device), loss_summary
-        return torch.stack(terms).sum(), loss_summary
+        return weights, terms, loss_summary
 
     def compute_triplet_loss(self, embeddings, visibility_scores, pids):
         vis = None

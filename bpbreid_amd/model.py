@@ -255,6 +255,26 @@ class BPBreID(nn.Module):
         # results up to summation order) and `spatial_features` is None -- what ImagePartBasedEngine sets, which never reads it
         # (the reference only feeds it to its feature-map visualisation, part_based_engine.py:82-84).
         self.materialize_spatial_features = True
+        self._eval_weights_frozen = False
+
+    def eval_weights_cached(self):
+        """Context manager for a run of eval-mode forwards between which no parameter or BatchNorm buffer changes (feature
+        extraction over a query / gallery set): the parameter-derived launches of the eval plan -- the affine of every BatchNorm
+        from its running statistics and the packing of the BN-folded convolution weights, 0.15-0.2 ms per forward -- run on the
+        first forward only.  Leaving the context (or a training forward / load_state_dict inside it) drops the cache."""
+        model = self
+
+        class _Ctx:
+            def __enter__(self_):
+                model._eval_weights_frozen = True
+                for pl in model._plans.values():
+                    pl.eval_weights_ready = False
+                return model
+
+            def __exit__(self_, *exc):
+                model._eval_weights_frozen = False
+                return False
+        return _Ctx()
 
     # ---------------------------------------------------------------- flat arenas
     def flatten_parameters(self):
@@ -449,6 +469,14 @@ class _ModelPlan:
         else:
             self.cls_p = [(_Bn(pc.bn, False), _Lin(pc.classifier)) for pc in m.parts_identity_classifier]
 
+    def eval_param_launches(self):
+        """Number of leading launches of the eval plan that only read parameters / BatchNorm buffers."""
+        k = 0
+        meta = self.net.plan_eval[2]
+        while k < len(meta) and meta[k]['label'] in ('bn_eval_affine_batched', 'pack_weights'):
+            k += 1
+        return k
+
     # ---------------------------------------------------------------- head without the concatenated map
     @staticmethod
     def _bilinear_tables(nout, nin):
@@ -576,8 +604,17 @@ class _ModelPlan:
             self._init_lowres()
         self.low = low
         lr = self.lr if low else None
+        # eval plan: its leading launches (BatchNorm affines from the running statistics, packing of the BN-folded weights) depend
+        # on the parameters only -- skipped while the model says they cannot have changed (BPBreID.eval_weights_cached)
+        first = 0
+        if training:
+            self.eval_weights_ready = False
+        elif m._eval_weights_frozen:
+            if getattr(self, 'eval_weights_ready', False):
+                first = self.eval_param_launches()
+            self.eval_weights_ready = True
         if low:
-            net.run(net.plan_train if training else net.plan_eval, 0, lr.cut['train' if training else 'eval'])
+            net.run(net.plan_train if training else net.plan_eval, first, lr.cut['train' if training else 'eval'])
             if training:
                 m._arena['ibuf'] += 1
             x = None
@@ -593,7 +630,7 @@ class _ModelPlan:
             net.run(net.plan_train)
             m._arena['ibuf'] += 1                      # every BatchNorm's num_batches_tracked
         else:
-            net.run(net.plan_eval)
+            net.run(net.plan_eval, first)
         if low or training:
             pass
         elif x is not fresh:

@@ -240,6 +240,7 @@ PROTOS = {
     'bpb_mask_preprocess': 'pppiiiiiiiiiffpp', 'bpb_bn_eval_affine_batched': 'piifp',
     'bpb_eval_rank': 'pppppiiiipppp', 'bpb_re_ranking': 'pppiiiifip', 'bpb_re_ranking_gpu_workspace': 'iiiipp',
     'bpb_re_ranking_gpu': 'pppiiiifpppp', 'bpb_eval_rank_gpu': 'pppppiiippppp',
+    'bpb_weighted_sum': 'ppipp', 'bpb_scalar_fanout': 'ppipp',
     'bpb_lowres_stats_rows': 'piip', 'bpb_lowres_stats': 'ppiiipp', 'bpb_lowres_upsample_sum': 'ppipppiiiip',
     'bpb_lowres_adjoint': 'ppipppiiiip', 'bpb_lowres_dx': 'ppiiiiii' + 'p' * 11,
 }
@@ -255,5 +256,5 @@ EXPORTS = [
     'bpb_fill', 'bpb_plan_run', 'bpb_plan_run_timed', 'bpb_part_distance', 'bpb_part_distance_fill', 'bpb_l2_normalize_rows', 'bpb_eval_rank',
     'bpb_mask_preprocess', 'bpb_re_ranking', 'bpb_re_ranking_gpu', 'bpb_re_ranking_gpu_workspace', 'bpb_eval_rank_gpu', 'bpb_bn_eval_affine_batched', 'bpb_resize_masks', 'bpb_attention_from_masks', 'bpb_conv_s1_init', 'bpb_conv_s1', 'bpb_wgrad16_init', 'bpb_conv_wgrad16', 'bpb_wgrad1x1_init', 'bpb_conv_wgrad1x1', 'bpb_fuse_fwd_multi', 'bpb_term_bwd_multi', 'bpb_bn_finalize_multi',
     'bpb_bn_bwd_finalize_multi', 'bpb_wgrad_reduce_multi',
-    'bpb_lowres_stats_rows', 'bpb_lowres_stats', 'bpb_lowres_upsample_sum', 'bpb_lowres_adjoint', 'bpb_lowres_dx',
+    'bpb_weighted_sum', 'bpb_scalar_fanout', 'bpb_lowres_stats_rows', 'bpb_lowres_stats', 'bpb_lowres_upsample_sum', 'bpb_lowres_adjoint', 'bpb_lowres_dx',
 ]

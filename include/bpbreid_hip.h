@@ -519,6 +519,10 @@ int bpb_ce_weight_grad(const float* row_loss, const float* w, const float* gloss
 int bpb_part_triplet_bwd(const float* emb, long se_n, long se_k, const float* gsq, const float* gscale, float gmul, int N,
                          int K, int D, float* demb, long sd_n, long sd_k, int accumulate, hipStream_t stream);
 int bpb_scale(const float* x, const float* alpha_dev, float alpha, float* y, long n, int accumulate, hipStream_t stream);
+/* loss = sum_i w_i * term_i over n <= 8 device scalars (GiLt_loss.py:45-76, part_based_engine.py:126); h_terms / h_weights are
+ * HOST arrays of n device pointers / weights.  bpb_scalar_fanout: out[i] = gloss[0] * w_i (the backward of the sum) */
+int bpb_weighted_sum(const float* const* h_terms, const float* h_weights, int n, float* out, hipStream_t stream);
+int bpb_scalar_fanout(const float* gloss, const float* h_weights, int n, float* out, hipStream_t stream);
 
 /* ---- optimizer step: torchreid/optim/optimizer.py:113-119 (torch.optim.Adam, coupled weight decay) ------------------ */
 int bpb_adam_step(float* p, const float* g, float* m, float* v, const long* blk_off, const int* blk_len, int nblocks,

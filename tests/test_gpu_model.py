@@ -525,6 +525,36 @@ def test_two_rank_data_parallel_matches_single_process(tmp_path):
     assert abs(r2['config']['final_loss'] - r1['config']['final_loss']) <= 2e-4 * abs(r1['config']['final_loss']), (r1, r2)
 
 
+def test_eval_weight_cache_equals_uncached_and_is_dropped_by_training():
+    """BPBreID.eval_weights_cached (what engine.feature_extraction wraps its loop in): inside the context the parameter-derived
+    launches of the eval plan run on the first forward only -- same outputs bit for bit; a training step inside the context
+    invalidates the cache, the next eval forward sees the new weights."""
+    k, d, n, h, w, ncls = 5, 64, 8, 64, 32, 16
+    model = Cm.fill_state_dict_(bpbreid(ncls, config=Cm.make_cfg('hrnet_w8', k, d), pretrained=False)).to(DEV)
+    eng = ImagePartBasedEngine(model, optimizer=FusedAdam(model, lr=1e-2), losses_weights=WEIGHTS_MARKET, mask_filtering_training=True)
+    imgs, masks, pids = Cm.synth_batch(n, h, w, k, ncls)
+    data = {'image': imgs.to(DEV), 'mask': masks.to(DEV), 'pid': pids.to(DEV)}
+    feat = lambda: eng.extract_test_embeddings(model(data['image'], external_parts_masks=data['mask']))[0].clone()
+    model.eval()
+    with torch.no_grad():
+        base = feat()
+        plan = next(iter(model._plans.values()))
+        assert plan.eval_param_launches() == 2
+        with model.eval_weights_cached():
+            a, b = feat(), feat()
+            assert plan.eval_weights_ready and torch.equal(a, base) and torch.equal(b, base)
+    with model.eval_weights_cached():
+        with torch.no_grad():
+            feat()
+        eng.forward_backward(data)                   # a training step inside the context: running statistics and weights move
+        model.eval()
+        with torch.no_grad():
+            c = feat()
+    with torch.no_grad():
+        ref = feat()                                  # outside the context: everything recomputed
+    assert torch.equal(c, ref) and not torch.equal(c, base)
+
+
 @pytest.mark.parametrize('rerank', [False, True])
 def test_engine_evaluate_end_to_end_on_device_matches_the_oracle(rerank):
     """ImagePartBasedEngine.evaluate (engine.py:433-437,558; part_based_engine.py:211-240): normalisation, part-based distance,

@@ -20,9 +20,12 @@ model.materialize_spatial_features = os.environ.get('BPB_FWD_SPATIAL', '0') == '
 imgs, masks, _ = Cm.synth_batch(n, h, w, k, 751)
 imgs, masks = imgs.to(dev), masks.to(dev)
 res = {}
+import contextlib                                             # noqa: E402
 for mode in os.environ.get('BPB_FWD_MODES', 'eval,train').split(','):
     model.train(mode == 'train')
-    with torch.no_grad():
+    # eval: like the engine's feature extraction, the parameter-derived launches (BatchNorm affines, weight packing) run once
+    cached = model.eval_weights_cached() if (mode == 'eval' and os.environ.get('BPB_FWD_CACHE', '1') != '0') else contextlib.nullcontext()
+    with torch.no_grad(), cached:
         for _ in range(3):
             model(imgs, external_parts_masks=masks)
         torch.cuda.synchronize()
