@@ -6,6 +6,8 @@ authors' checkpoints load unchanged, and (b) an ``emit(net, x)`` method that rec
 ``graph.Net`` launch plan instead of executing nn.Module calls.  The nn.Conv2d / nn.BatchNorm2d children
 are never called: they only own the tensors (which live in one flat arena, see model.py).
 """
+import os
+
 import torch.nn as nn
 
 
@@ -133,26 +135,44 @@ class MultiResModule(nn.Module):
         # folded into the fuse read (no upsampled tensor is ever written).  The paths into target i (up to three small convs
         # each, 16 convs + 24 BatchNorm/fuse launches in a 4-branch module) and its final fuse are recorded on stream slot i:
         # recorded on one stream they were ~10 ms of strictly serial small launches per train step.
-        net.fork(nb)
-        outs = []
-        for i, row in enumerate(self.fuse_layers):
-            net.set_slot(i)
-            terms = []
-            for j, x in enumerate(xs):
-                if j == i:
-                    terms.append((x, 0))
-                elif j > i:
-                    terms.append((_emit_cb(net, x, row[j][0], row[j][1]), j - i))
-                else:
-                    t = x
-                    steps = list(row[j])
-                    for k, st in enumerate(steps):
-                        c = _emit_cb(net, t, st[0], st[1])
-                        if k < len(steps) - 1:
-                            t = net.fuse([(c, 0)], relu=True)
-                        else:
-                            terms.append((c, 0))
-            outs.append(net.fuse(terms, relu=True))
+        def path(i, j, x):
+            row = self.fuse_layers[i]
+            if j > i:
+                return (_emit_cb(net, x, row[j][0], row[j][1]), j - i)
+            t = x
+            steps = list(row[j])
+            for k, st in enumerate(steps):
+                c = _emit_cb(net, t, st[0], st[1])
+                if k < len(steps) - 1:
+                    t = net.fuse([(c, 0)], relu=True)
+            return (c, 0)
+
+        if os.environ.get('BPB_EXCHANGE_PATHS', '1') != '0' and nb * (nb - 1) <= 16:
+            # Round 3: every PATH j -> i is its own chain of a first region (nb * (nb - 1) chains), the nb final sums form a
+            # second one.  Recorded per target, the three down-paths into the deepest branch (3 + 2 + 1 strided convolutions)
+            # were six convolution rounds of the lock-step merge; per path, step k of every path shares a round: three rounds, each
+            # a grouped launch over up to six problems instead of single launches that cannot fill the chip (22 us at 54 TFLOP/s).
+            net.fork(nb * (nb - 1))
+            produced, slot = {}, 0
+            for i in range(nb):
+                for j, x in enumerate(xs):
+                    if j != i:
+                        net.set_slot(slot)
+                        slot += 1
+                        produced[(i, j)] = path(i, j, x)
+            net.set_slot(0)
+            net.join(nb * (nb - 1))
+            net.fork(nb)
+            outs = []
+            for i in range(nb):
+                net.set_slot(i)
+                outs.append(net.fuse([(x, 0) if j == i else produced[(i, j)] for j, x in enumerate(xs)], relu=True))
+        else:
+            net.fork(nb)
+            outs = []
+            for i in range(nb):
+                net.set_slot(i)
+                outs.append(net.fuse([(x, 0) if j == i else path(i, j, x) for j, x in enumerate(xs)], relu=True))
         net.set_slot(0)
         if last:
             net.join(nb)

@@ -191,7 +191,7 @@ class Net:
 
     def fork(self, nslots):
         """Branches recorded with set_slot(0..nslots-1) are independent of each other until the matching join()."""
-        assert self.cur_slot == 0 and 1 <= nslots <= 4
+        assert self.cur_slot == 0 and 1 <= nslots <= 16
         if nslots > 1:
             self._nregions += 1
             self.cur_region = self._nregions
