@@ -46,7 +46,7 @@ def test_ctypes_mirrors_have_the_c_layout(tmp_path):
     pairs = {'BpbConvProb': nv.ConvProb, 'BpbConvS1Prob': nv.ConvS1Prob, 'BpbS1BnBwd': nv.S1BnBwd, 'BpbBnFinDesc': nv.BnFinDesc, 'BpbBnBwdFinDesc': nv.BnBwdFinDesc,
              'BpbWgradReduceDesc': nv.WgradReduceDesc, 'BpbWgradProb': nv.WgradProb, 'BpbPackProb': nv.PackProb, 'BpbFuseArgs': nv.FuseArgs,
              'BpbTermBwdArgs': nv.TermBwdArgs, 'BpbBilinearArgs': nv.BilinearArgs, 'BpbBilinearBwdDesc': nv.BilinearBwdDesc, 'BpbWgrad1x1Prob': nv.Wgrad1x1Prob, 'BpbGemmProb': nv.GemmProb, 'BpbBnFinalizeArgs': nv.BnFinalizeArgs,
-             'BpbBnEvalDesc': nv.BnEvalDesc, 'BpbPlanOp': nv.PlanOp}
+             'BpbBnEvalDesc': nv.BnEvalDesc, 'BpbPlanOp': nv.PlanOp, 'BpbHeadBranch': nv.HeadBranch}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "bpbreid_hip.h"', 'int main(void) {']
     for cname, cls in pairs.items():
         lines.append('printf("%s.sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
@@ -461,3 +461,48 @@ def test_gemm_batch_splits_long_join_series_into_accumulating_launches(monkeypat
     assert [len(l) for l in launches] == [nv.GEMM_MAX, 31 - nv.GEMM_MAX]
     assert launches[0][0] == (0, 0, 100) and launches[0][1] == (0, 0, 200) and all(p == (1, 0, 200) for p in launches[0][2:])
     assert launches[1][0] == (0, 1, 200) and all(p == (1, 0, 200) for p in launches[1][1:])
+
+
+def test_lowres_head_tables_reproduce_the_materialised_map_statistics():
+    """Host side of the head without the concatenated map (model._ModelPlan._bilinear_tables, csrc/head_lowres.hip): the fp32
+    replica of the align_corners interpolation matrix must be torch's own (F.interpolate), U^T U must be tridiagonal, and the
+    per-channel sum / sum of squares of the up-sampled map must follow from the low-resolution tensor with the column sums
+    and the three bands only -- the identities the statistics and gradient kernels rely on."""
+    import numpy as np
+    import torch
+    from bpbreid_amd.model import _ModelPlan
+    g = torch.Generator().manual_seed(5)
+    for (H, W, hs, ws) in ((64, 32, 32, 16), (64, 32, 8, 4), (96, 32, 12, 4), (24, 16, 3, 2), (16, 8, 16, 8)):
+        sh, w1h, gh = _ModelPlan._bilinear_tables(H, hs)
+        sw, w1w, gw = _ModelPlan._bilinear_tables(W, ws)
+        x = torch.randn(2, 3, hs, ws, generator=g, dtype=torch.float64)
+        up = torch.nn.functional.interpolate(x, (H, W), mode='bilinear', align_corners=True)
+        # interpolation matrices rebuilt from the tables' own recipe agree with torch
+        def U(nout, nin, scale):
+            m = np.zeros((nout, nin))
+            for o in range(nout):
+                f = np.float32(np.float32(scale) * np.float32(o))
+                i0 = int(f)
+                i1 = i0 + (1 if i0 < nin - 1 else 0)
+                l1 = np.float32(f - np.float32(i0))
+                m[o, i0] += float(np.float32(1) - l1)
+                m[o, i1] += float(l1)
+            return torch.from_numpy(m)
+        Uh, Uw = U(H, hs, sh), U(W, ws, sw)
+        # (fp32 weights, like ATen's fp32 kernel: against the fp64 interpolation they differ by the rounding of the scale)
+        up32 = torch.nn.functional.interpolate(x.float(), (H, W), mode='bilinear', align_corners=True).double()
+        mine = torch.einsum('pi,qj,ncij->ncpq', Uh, Uw, x)
+        assert (mine - up32).abs().max() < 2e-6 and (mine - up).abs().max() < 2e-5
+        up = mine
+        assert np.allclose(Uh.sum(0).numpy(), w1h, atol=1e-6) and np.allclose(Uw.sum(0).numpy(), w1w, atol=1e-6)
+        # sum and sum of squares of the up-sampled map from the low-resolution tensor
+        s1 = torch.einsum('i,j,ncij->nc', torch.from_numpy(w1h).double(), torch.from_numpy(w1w).double(), x)
+        assert torch.allclose(s1, up.sum(dim=(2, 3)), atol=1e-4)
+        gx = torch.zeros_like(x)
+        for i in range(hs):
+            for j in range(ws):
+                for di in (-1, 0, 1):
+                    for dj in (-1, 0, 1):
+                        if 0 <= i + di < hs and 0 <= j + dj < ws:
+                            gx[:, :, i, j] += float(gh[i, di + 1]) * float(gw[j, dj + 1]) * x[:, :, i + di, j + dj]
+        assert torch.allclose((x * gx).sum(dim=(2, 3)), (up * up).sum(dim=(2, 3)), rtol=1e-5, atol=1e-4)
