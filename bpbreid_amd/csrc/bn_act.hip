@@ -115,12 +115,10 @@ __global__ __launch_bounds__(1024) void bpb_bn_finalize_kernel(const double* __r
                          running_mean, running_var);
 }
 
-__global__ __launch_bounds__(1024) void bpb_bn_finalize_multi_kernel(const BpbBnFinDesc* __restrict__ descs, int n)
+__global__ __launch_bounds__(1024) void bpb_bn_finalize_multi_kernel(const BpbBnFinDesc* __restrict__ descs, BpbBlkBegins bb)
 {
     __shared__ double red[2][BPB_FIN_LANES][BPB_FIN_CH];
-    int di = 0;
-    for (int i = 1; i < n; ++i)
-        if ((int)blockIdx.x >= descs[i].blk_begin) di = i;
+    const int di = bpb_find_problem(bb, (int)blockIdx.x);
     const BpbBnFinDesc D = descs[di];
     bpb_bn_finalize_body(blockIdx.x - D.blk_begin, red, D.partials, D.nparts, D.C, D.count, D.gamma, D.beta, D.eps, D.momentum, D.scale,
                          D.shift, D.mean, D.invstd, D.running_mean, D.running_var);
@@ -293,19 +291,10 @@ __global__ __launch_bounds__(256) void bpb_fuse_fwd_kernel(BpbFuseArgs A)
     bpb_fuse_fwd_body(A, blockIdx.x, gridDim.x);
 }
 
-// grouped launches: block -> record through the blk_begin prefix (<= 16 records: linear scan of scalar loads)
-template <typename D>
-__device__ __forceinline__ int bpb_find_record(const D* __restrict__ descs, int n, int bid)
+// grouped launches: block -> record through the blk_begin prefix held in the kernel arguments (bpb_common.h)
+__global__ __launch_bounds__(256) void bpb_fuse_fwd_multi_kernel(const BpbFuseArgs* __restrict__ descs, BpbBlkBegins bb)
 {
-    int di = 0;
-    for (int i = 1; i < n; ++i)
-        if (bid >= descs[i].blk_begin) di = i;
-    return di;
-}
-
-__global__ __launch_bounds__(256) void bpb_fuse_fwd_multi_kernel(const BpbFuseArgs* __restrict__ descs, int n)
-{
-    const BpbFuseArgs A = descs[bpb_find_record(descs, n, blockIdx.x)];
+    const BpbFuseArgs A = descs[bpb_find_problem(bb, (int)blockIdx.x)];
     bpb_fuse_fwd_body(A, blockIdx.x - A.blk_begin, A.nblk);
 }
 
@@ -537,12 +526,10 @@ __global__ __launch_bounds__(1024) void bpb_bn_bwd_finalize_kernel(const double*
     bpb_bn_bwd_finalize_body(blockIdx.x, red, partials, nparts, C, count, dgamma, dbeta, accumulate, c1, c2);
 }
 
-__global__ __launch_bounds__(1024) void bpb_bn_bwd_finalize_multi_kernel(const BpbBnBwdFinDesc* __restrict__ descs, int n)
+__global__ __launch_bounds__(1024) void bpb_bn_bwd_finalize_multi_kernel(const BpbBnBwdFinDesc* __restrict__ descs, BpbBlkBegins bb)
 {
     __shared__ double red[2][BPB_FIN_LANES][BPB_FIN_CH];
-    int di = 0;
-    for (int i = 1; i < n; ++i)
-        if ((int)blockIdx.x >= descs[i].blk_begin) di = i;
+    const int di = bpb_find_problem(bb, (int)blockIdx.x);
     const BpbBnBwdFinDesc D = descs[di];
     bpb_bn_bwd_finalize_body(blockIdx.x - D.blk_begin, red, D.partials, D.nparts, D.C, D.count, D.dgamma, D.dbeta, D.accumulate, D.c1, D.c2);
 }
@@ -591,10 +578,10 @@ __global__ __launch_bounds__(256) void bpb_term_bwd_bn_apply_kernel(BpbTermBwdAr
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void bpb_term_bwd_multi_kernel(const BpbTermBwdArgs* __restrict__ descs, int n)
+__global__ __launch_bounds__(256) void bpb_term_bwd_multi_kernel(const BpbTermBwdArgs* __restrict__ descs, BpbBlkBegins bb)
 {
     __shared__ double red[MODE == 1 ? 256 * 8 : 1];
-    const BpbTermBwdArgs A = descs[bpb_find_record(descs, n, blockIdx.x)];
+    const BpbTermBwdArgs A = descs[bpb_find_problem(bb, (int)blockIdx.x)];
     const int blk = blockIdx.x - A.blk_begin;
     if (MODE == 0) bpb_term_bwd_identity_body(A, blk, A.nblk);
     else if (MODE == 1) bpb_term_bwd_bn_reduce_body(A, blk, A.nblk, red);
@@ -711,7 +698,7 @@ int bpb_fuse_fwd_multi(const BpbFuseArgs* d_descs, const BpbFuseArgs* h_descs, i
         blk += a->nblk;
     }
     BPB_REQUIRE(blk == total_blocks, "bpb_fuse_fwd_multi: block count mismatch");
-    hipLaunchKernelGGL(bpb_fuse_fwd_multi_kernel, dim3(total_blocks), dim3(256), 0, stream, d_descs, n);
+    hipLaunchKernelGGL(bpb_fuse_fwd_multi_kernel, dim3(total_blocks), dim3(256), 0, stream, d_descs, bpb_blk_begins(h_descs, n));
     BPB_LAUNCH_OK();
     return 0;
 }
@@ -728,9 +715,10 @@ int bpb_term_bwd_multi(const BpbTermBwdArgs* d_descs, const BpbTermBwdArgs* h_de
         blk += h_descs[i].nblk;
     }
     BPB_REQUIRE(blk == total_blocks, "bpb_term_bwd_multi: block count mismatch");
-    if (mode == 0) hipLaunchKernelGGL(bpb_term_bwd_multi_kernel<0>, dim3(total_blocks), dim3(256), 0, stream, d_descs, n);
-    else if (mode == 1) hipLaunchKernelGGL(bpb_term_bwd_multi_kernel<1>, dim3(total_blocks), dim3(256), 0, stream, d_descs, n);
-    else if (mode == 2) hipLaunchKernelGGL(bpb_term_bwd_multi_kernel<2>, dim3(total_blocks), dim3(256), 0, stream, d_descs, n);
+    const BpbBlkBegins bb = bpb_blk_begins(h_descs, n);
+    if (mode == 0) hipLaunchKernelGGL(bpb_term_bwd_multi_kernel<0>, dim3(total_blocks), dim3(256), 0, stream, d_descs, bb);
+    else if (mode == 1) hipLaunchKernelGGL(bpb_term_bwd_multi_kernel<1>, dim3(total_blocks), dim3(256), 0, stream, d_descs, bb);
+    else if (mode == 2) hipLaunchKernelGGL(bpb_term_bwd_multi_kernel<2>, dim3(total_blocks), dim3(256), 0, stream, d_descs, bb);
     else return bpb_set_error(-1, "bpb_term_bwd_multi: mode %d", mode);
     BPB_LAUNCH_OK();
     return 0;
@@ -746,7 +734,7 @@ int bpb_bn_finalize_multi(const BpbBnFinDesc* d_descs, const BpbBnFinDesc* h_des
         blk += bpb_cdiv(h_descs[i].C, BPB_FIN_CH);
     }
     BPB_REQUIRE(blk == total_blocks, "bpb_bn_finalize_multi: block count mismatch");
-    hipLaunchKernelGGL(bpb_bn_finalize_multi_kernel, dim3(total_blocks), dim3(1024), 0, stream, d_descs, n);
+    hipLaunchKernelGGL(bpb_bn_finalize_multi_kernel, dim3(total_blocks), dim3(1024), 0, stream, d_descs, bpb_blk_begins(h_descs, n));
     BPB_LAUNCH_OK();
     return 0;
 }
@@ -761,7 +749,7 @@ int bpb_bn_bwd_finalize_multi(const BpbBnBwdFinDesc* d_descs, const BpbBnBwdFinD
         blk += bpb_cdiv(h_descs[i].C, BPB_FIN_CH);
     }
     BPB_REQUIRE(blk == total_blocks, "bpb_bn_bwd_finalize_multi: block count mismatch");
-    hipLaunchKernelGGL(bpb_bn_bwd_finalize_multi_kernel, dim3(total_blocks), dim3(1024), 0, stream, d_descs, n);
+    hipLaunchKernelGGL(bpb_bn_bwd_finalize_multi_kernel, dim3(total_blocks), dim3(1024), 0, stream, d_descs, bpb_blk_begins(h_descs, n));
     BPB_LAUNCH_OK();
     return 0;
 }

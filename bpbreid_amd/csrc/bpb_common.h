@@ -41,6 +41,31 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline int bpb_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Grouped launches: block -> problem.  The first-block prefix of the (<= 16) problems travels BY VALUE in the kernel-argument
+// segment: a workgroup finds its problem with scalar compares and then loads ONE descriptor, instead of a chain of dependent
+// loads of descs[i].blk_begin from device memory in front of the descriptor load (two memory round trips at the start of every
+// workgroup; the element-wise kernels live ~10 us).
+struct BpbBlkBegins {
+    int begin[16];
+};
+template <typename D>
+static inline BpbBlkBegins bpb_blk_begins(const D* h_descs, int n)
+{
+    BpbBlkBegins b;
+    for (int i = 0; i < 16; ++i) b.begin[i] = i < n ? h_descs[i].blk_begin : 0x7fffffff;
+    return b;
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ int bpb_find_problem(const BpbBlkBegins& bb, int bid)
+{
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < 16; ++i)
+        if (bid >= bb.begin[i]) pi = i;
+    return pi;
+}
+#endif
+
 // ---------------------------------------------------------------------------------------
 // Descriptor of one implicit-GEMM convolution problem.  Lives in DEVICE memory; a launch takes an
 // array of them ("grouped launch": independent branches of an HRNet module share one launch so

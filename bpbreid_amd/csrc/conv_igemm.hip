@@ -33,13 +33,11 @@ __device__ __forceinline__ unsigned bpb_fdiv(unsigned x, unsigned d, unsigned ma
 }
 
 template <int NT, bool C4, int MTr>
-__global__ __launch_bounds__(256, 2) void bpb_conv_igemm_kernel(const BpbConvProb* __restrict__ probs, int nprobs)
+__global__ __launch_bounds__(256, 2) void bpb_conv_igemm_kernel(const BpbConvProb* __restrict__ probs, BpbBlkBegins bb)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int bid = blockIdx.x;
-    int pi = 0;
-    for (int i = 1; i < nprobs; ++i)
-        if (bid >= probs[i].blk_begin) pi = i;
+    const int pi = bpb_find_problem(bb, bid);
     const BpbConvProb P = probs[pi];   // by value: the whole descriptor sits in SGPRs, no reloads in the loops
     bid -= P.blk_begin;
 
@@ -507,13 +505,11 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_igemm_kernel(const BpbConvPro
 // ---------------------------------------------------------------------------------------
 
 template <int TG, int NTW>   // TG = taps per group (9 for spatial filters, 1 for 1x1), NTW = 32-wide co sub-tiles
-__global__ __launch_bounds__(256, 2) void bpb_conv_wgrad_kernel(const BpbWgradProb* __restrict__ probs, int nprobs)
+__global__ __launch_bounds__(256, 2) void bpb_conv_wgrad_kernel(const BpbWgradProb* __restrict__ probs, BpbBlkBegins bb)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int bid = blockIdx.x;
-    int pi = 0;
-    for (int i = 1; i < nprobs; ++i)
-        if (bid >= probs[i].blk_begin) pi = i;
+    const int pi = bpb_find_problem(bb, bid);
     const BpbWgradProb P = probs[pi];
     bid -= P.blk_begin;
 
@@ -757,12 +753,10 @@ __global__ __launch_bounds__(256) void bpb_wgrad_reduce_kernel(const float* __re
 }
 
 // grouped: the slab reductions of the convolutions of one module step in one launch (blk_begin prefix)
-__global__ __launch_bounds__(256) void bpb_wgrad_reduce_multi_kernel(const BpbWgradReduceDesc* __restrict__ descs, int n)
+__global__ __launch_bounds__(256) void bpb_wgrad_reduce_multi_kernel(const BpbWgradReduceDesc* __restrict__ descs, BpbBlkBegins bb)
 {
     __shared__ float red[256];
-    int di = 0;
-    for (int i = 1; i < n; ++i)
-        if ((int)blockIdx.x >= descs[i].blk_begin) di = i;
+    const int di = bpb_find_problem(bb, (int)blockIdx.x);
     const BpbWgradReduceDesc D = descs[di];
     bpb_wgrad_reduce_body(blockIdx.x - D.blk_begin, red, D.ws, D.dw, D.nsplit, D.T, D.Cin, D.Cin_real, D.Cout, D.accumulate, D.pad_);
 }
@@ -884,7 +878,7 @@ int bpb_conv_igemm(const BpbConvProb* d_probs, const BpbConvProb* h_probs, int n
     BPB_REQUIRE(lds <= 160 * 1024, "bpb_conv_igemm: halo tile needs %d B of LDS", lds);
     if (nblk == 0) return 0;
 #define BPB_CONV_LAUNCH(NT, C4, MT) \
-    hipLaunchKernelGGL((bpb_conv_igemm_kernel<NT, C4, MT>), dim3(nblk), dim3(256), lds, stream, d_probs, nprobs)
+    hipLaunchKernelGGL((bpb_conv_igemm_kernel<NT, C4, MT>), dim3(nblk), dim3(256), lds, stream, d_probs, bpb_blk_begins(h_probs, nprobs))
 #define BPB_CONV_LAUNCH_MT(NT, C4) \
     do { if (mt == 1) { BPB_CONV_LAUNCH(NT, C4, 1); } else { BPB_CONV_LAUNCH(NT, C4, 2); } } while (0)
     if (c4 && nt == 1) { BPB_CONV_LAUNCH_MT(1, true); }
@@ -927,7 +921,7 @@ int bpb_conv_wgrad(const BpbWgradProb* d_probs, const BpbWgradProb* h_probs, int
     BPB_REQUIRE(lds <= 160 * 1024, "bpb_conv_wgrad: needs %d B of LDS", lds);
     if (nblk == 0) return 0;
 #define BPB_WG_LAUNCH(TG, NTW) \
-    hipLaunchKernelGGL((bpb_conv_wgrad_kernel<TG, NTW>), dim3(nblk), dim3(256), lds, stream, d_probs, nprobs)
+    hipLaunchKernelGGL((bpb_conv_wgrad_kernel<TG, NTW>), dim3(nblk), dim3(256), lds, stream, d_probs, bpb_blk_begins(h_probs, nprobs))
     if (ntw == 1 && h_probs[0].T == 1) { BPB_WG_LAUNCH(1, 1); }
     else if (ntw == 1) { BPB_WG_LAUNCH(9, 1); }
     else if (ntw == 2) { BPB_WG_LAUNCH(1, 2); }
@@ -964,7 +958,7 @@ int bpb_wgrad_reduce_multi(const BpbWgradReduceDesc* d_descs, const BpbWgradRedu
         blk += bpb_cdiv(total, 256 >> h_descs[i].pad_);
     }
     BPB_REQUIRE(blk == total_blocks, "bpb_wgrad_reduce_multi: block count mismatch");
-    hipLaunchKernelGGL(bpb_wgrad_reduce_multi_kernel, dim3(total_blocks), dim3(256), 0, stream, d_descs, n);
+    hipLaunchKernelGGL(bpb_wgrad_reduce_multi_kernel, dim3(total_blocks), dim3(256), 0, stream, d_descs, bpb_blk_begins(h_descs, n));
     BPB_LAUNCH_OK();
     return 0;
 }

@@ -43,15 +43,13 @@ __device__ unsigned long long* g_s1_trace = nullptr;
 #endif
 
 template <int NT, int MT, int R, int KG>   // KG = 8-channel k-groups per tap and pipeline stage: channel chunk CK = 8 * KG
-__global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob* __restrict__ probs, int nprobs)
+__global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob* __restrict__ probs, BpbBlkBegins bb)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int T = R * R, PAD = R / 2, CK = 8 * KG, NJ = T * KG;
     S1_TR(0);
     int bid = blockIdx.x;
-    int pi = 0;
-    for (int i = 1; i < nprobs; ++i)
-        if (bid >= probs[i].blk_begin) pi = i;
+    const int pi = bpb_find_problem(bb, bid);
     const BpbConvS1Prob P = probs[pi];
     bid -= P.blk_begin;
     if (P.xr) {
@@ -515,8 +513,9 @@ int bpb_conv_s1(const BpbConvS1Prob* d_probs, const BpbConvS1Prob* h_probs, int 
     }
     BPB_REQUIRE(lds <= 160 * 1024, "bpb_conv_s1: needs %d B of LDS", lds);
     if (nblk == 0) return 0;
+    const BpbBlkBegins bb = bpb_blk_begins(h_probs, nprobs);
 #define BPB_S1_LAUNCH(NT, MT, RR, KG) \
-    hipLaunchKernelGGL((bpb_conv_s1_kernel<NT, MT, RR, KG>), dim3(nblk), dim3(256), lds, stream, d_probs, nprobs)
+    hipLaunchKernelGGL((bpb_conv_s1_kernel<NT, MT, RR, KG>), dim3(nblk), dim3(256), lds, stream, d_probs, bb)
 #define BPB_S1_K(NT, MT, RR) \
     do { if (ck == 8) { BPB_S1_LAUNCH(NT, MT, RR, 1); } else if (ck == 16) { BPB_S1_LAUNCH(NT, MT, RR, 2); } else { BPB_S1_LAUNCH(NT, MT, RR, 4); } } while (0)
 #define BPB_S1_R(NT, MT) \

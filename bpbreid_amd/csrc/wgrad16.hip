@@ -32,14 +32,12 @@ __device__ __forceinline__ unsigned wg_fdiv(unsigned x, unsigned d, unsigned mag
 // Stride 2 (SA = 2): the staged x image of a 64-pixel output tile is (2*TH + 1) x (2*TW + 1) pixels (HWC = 9 or 17), 37 KB per
 // buffer for 32 input channels -> one workgroup per CU; the k-loop is identical (pixel (a, b) reads halo pixel (2a + r, 2b + s)).
 template <int NKS, int HWC, int SA>   // NKS k-steps of 4 pixels per staged tile (16: 64-pixel tiles); HWC = (TW - 1) * SA + 3
-__global__ __launch_bounds__(256, SA == 1 ? 2 : 1) void bpb_wgrad16_kernel(const BpbWgradProb* __restrict__ probs, int nprobs)
+__global__ __launch_bounds__(256, SA == 1 ? 2 : 1) void bpb_wgrad16_kernel(const BpbWgradProb* __restrict__ probs, BpbBlkBegins bb)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TG = 9, S = 3;
     int bid = blockIdx.x;
-    int pi = 0;
-    for (int i = 1; i < nprobs; ++i)
-        if (bid >= probs[i].blk_begin) pi = i;
+    const int pi = bpb_find_problem(bb, bid);
     const BpbWgradProb P = probs[pi];
     bid -= P.blk_begin;
     if (P.xr) {
@@ -247,7 +245,8 @@ int bpb_conv_wgrad16(const BpbWgradProb* d_probs, const BpbWgradProb* h_probs, i
     }
     BPB_REQUIRE(lds <= 160 * 1024, "bpb_conv_wgrad16: needs %d B of LDS", lds);
     if (nblk == 0) return 0;
-#define BPB_W16(HWC_, SA_) hipLaunchKernelGGL((bpb_wgrad16_kernel<16, HWC_, SA_>), dim3(nblk), dim3(256), lds, stream, d_probs, nprobs)
+    const BpbBlkBegins bb = bpb_blk_begins(h_probs, nprobs);
+#define BPB_W16(HWC_, SA_) hipLaunchKernelGGL((bpb_wgrad16_kernel<16, HWC_, SA_>), dim3(nblk), dim3(256), lds, stream, d_probs, bb)
     if (sa == 1 && ltw == 2) BPB_W16(6, 1);
     else if (sa == 1) BPB_W16(10, 1);
     else if (ltw == 2) BPB_W16(9, 2);

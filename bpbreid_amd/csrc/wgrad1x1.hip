@@ -15,14 +15,12 @@
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-__global__ __launch_bounds__(256, 1) void bpb_wgrad1x1_kernel(const BpbWgrad1x1Prob* __restrict__ probs, int nprobs)
+__global__ __launch_bounds__(256, 1) void bpb_wgrad1x1_kernel(const BpbWgrad1x1Prob* __restrict__ probs, BpbBlkBegins bb)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int MPIX = 32, NKS = MPIX / 4, PLANE = MPIX * 64;      // bytes of one 16-channel plane of a pixel tile
     int bid = blockIdx.x;
-    int pi = 0;
-    for (int i = 1; i < nprobs; ++i)
-        if (bid >= probs[i].blk_begin) pi = i;
+    const int pi = bpb_find_problem(bb, bid);
     const BpbWgrad1x1Prob P = probs[pi];
     bid -= P.blk_begin;
     const int lane = threadIdx.x & 63;
@@ -181,7 +179,7 @@ int bpb_conv_wgrad1x1(const BpbWgrad1x1Prob* d_probs, const BpbWgrad1x1Prob* h_p
         lds = l > lds ? l : lds;
     }
     if (nblk == 0) return 0;
-    hipLaunchKernelGGL(bpb_wgrad1x1_kernel, dim3(nblk), dim3(256), lds, stream, d_probs, nprobs);
+    hipLaunchKernelGGL(bpb_wgrad1x1_kernel, dim3(nblk), dim3(256), lds, stream, d_probs, bpb_blk_begins(h_probs, nprobs));
     BPB_LAUNCH_OK();
     return 0;
 }
