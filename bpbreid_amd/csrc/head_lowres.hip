@@ -191,40 +191,45 @@ __global__ __launch_bounds__(256) void lr_upsample_sum_kernel(const BpbHeadBranc
 }
 
 // out_b[n][j][q] = scale(n, j) * sum_p U_b[p][q] a[n][j][p]      a: [N][J][H*W], out_b: [N][J][Hs*Ws]
-// scale: 1, or (zinv given) the pooling normalisation of row j: 1/HW for j < 3, |zinv[n][j]| for the part rows
+// scale: 1, or (zinv given) the pooling normalisation of row j: 1/HW for j < 3, |zinv[n][j]| for the part rows.
+// One workgroup per (branch, image, row j): the H x W plane is staged in LDS and resampled separably -- along W into
+// tmp[H][Ws], then along H -- so that no thread gathers more than one tent's support (a one-pass gather left the 8x
+// down-sampled branch with 324 serial iterations per thread: 74 us for 1.4 M outputs).
 __global__ __launch_bounds__(256) void lr_adjoint_kernel(const BpbHeadBranch* __restrict__ br, const float* __restrict__ a,
-                                                         const float* __restrict__ zinv, float* const* __restrict__ outs, int N, int J,
-                                                         int H, int W)
+                                                         const float* __restrict__ zinv, float* const* __restrict__ outs, int J, int H, int W)
 {
+    extern __shared__ float lr_smem[];                      // plane [H][W], then tmp [H][Ws]
     const BpbHeadBranch B = br[blockIdx.y];
-    float* out = outs[blockIdx.y];
+    const long nj = blockIdx.x;
+    const int jrow = (int)(nj % J);
     const int HWs = B.Hs * B.Ws;
-    const long total = (long)N * J * HWs;
-    const float inv_hw = 1.f / (float)(H * W);
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
-        const int q = (int)(i % HWs);
-        const long nj = i / HWs;
-        const int j = (int)(nj % J);
-        const int is = q / B.Ws, js = q - is * B.Ws;
-        const float* ap = a + nj * (long)H * W;
-        int hlo, hhi, wlo, whi;
-        lr_range(is, H, B.sh, hlo, hhi);
+    float* out = outs[blockIdx.y] + nj * HWs;
+    const float* ap = a + nj * (long)H * W;
+    const float sc = zinv ? (jrow < 3 ? 1.f / (float)(H * W) : fabsf(zinv[nj])) : 1.f;
+    if (B.Hs == H && B.Ws == W) {                           // the branch at the map's own resolution: a scaled copy
+        for (int i = threadIdx.x; i < HWs; i += 256) out[i] = ap[i] * sc;
+        return;
+    }
+    float* plane = lr_smem;
+    float* tmp = lr_smem + H * W;
+    for (int i = threadIdx.x; i < H * W; i += 256) plane[i] = ap[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < H * B.Ws; i += 256) {     // along W
+        const int h = i / B.Ws, js = i - h * B.Ws;
+        int wlo, whi;
         lr_range(js, W, B.sw, wlo, whi);
-        if (B.Hs == H) { hlo = hhi = is; }
-        if (B.Ws == W) { wlo = whi = js; }
-        float s = 0.f;
-        for (int h = hlo; h <= hhi; ++h) {
-            const float wh = B.Hs == H ? 1.f : lr_tent(h, is, B.Hs, B.sh);
-            if (wh == 0.f) continue;
-            float r = 0.f;
-            for (int w = wlo; w <= whi; ++w) {
-                const float ww = B.Ws == W ? 1.f : lr_tent(w, js, B.Ws, B.sw);
-                r += ww * ap[(long)h * W + w];
-            }
-            s += wh * r;
-        }
-        const float sc = zinv ? (j < 3 ? inv_hw : fabsf(zinv[nj])) : 1.f;
-        out[i] = s * sc;
+        float r = 0.f;
+        for (int w = wlo; w <= whi; ++w) r += lr_tent(w, js, B.Ws, B.sw) * plane[h * W + w];
+        tmp[i] = r;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HWs; i += 256) {          // along H
+        const int is = i / B.Ws, js = i - is * B.Ws;
+        int hlo, hhi;
+        lr_range(is, H, B.sh, hlo, hhi);
+        float r = 0.f;
+        for (int h = hlo; h <= hhi; ++h) r += lr_tent(h, is, B.Hs, B.sh) * tmp[h * B.Ws + js];
+        out[i] = r * sc;
     }
 }
 
@@ -402,9 +407,11 @@ int bpb_lowres_adjoint(const BpbHeadBranch* d_br, const BpbHeadBranch* h_br, int
                        float* const* d_outs, int N, int J, int H, int W, hipStream_t stream)
 {
     if (int rc = lr_check(h_br, nb, "bpb_lowres_adjoint")) return rc;
-    long most = 0;
-    for (int b = 0; b < nb; ++b) most = most > (long)N * J * h_br[b].Hs * h_br[b].Ws ? most : (long)N * J * h_br[b].Hs * h_br[b].Ws;
-    hipLaunchKernelGGL(lr_adjoint_kernel, dim3(lr_grid(most), nb), dim3(256), 0, stream, d_br, a, zinv, d_outs, N, J, H, W);
+    int wsmax = 1;
+    for (int b = 0; b < nb; ++b) wsmax = wsmax > h_br[b].Ws ? wsmax : h_br[b].Ws;
+    const int lds = (H * W + H * wsmax) * 4;
+    BPB_REQUIRE(lds <= 64 * 1024, "bpb_lowres_adjoint: a %d x %d plane needs %d B of LDS", H, W, lds);
+    hipLaunchKernelGGL(lr_adjoint_kernel, dim3(N * J, nb), dim3(256), lds, stream, d_br, a, zinv, d_outs, J, H, W);
     BPB_LAUNCH_OK();
     return 0;
 }
