@@ -31,7 +31,9 @@ __device__ __forceinline__ unsigned s1_fdiv(unsigned x, unsigned d, unsigned mag
 // Measurement build only (tools/s1_trace.py links it into a separate library; never part of libbpbreid_hip.so): every wave
 // stamps s_memtime at its phase boundaries -- entry, prologue done, first chunk landed, MFMA loop done, exit -- plus where it ran.
 __device__ unsigned long long* g_s1_trace = nullptr;
-#define S1_TR(i) do { if (g_s1_trace && (threadIdx.x & 63) == 0) g_s1_trace[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// (s_memtime counts shader cycles from a base of its own per CU; s_memrealtime is the chip-wide 100 MHz clock: slots 8, 9)
+#define S1_TR(i) do { if (g_s1_trace && (threadIdx.x & 63) == 0) { unsigned long long* t_ = g_s1_trace + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16; \
+        t_[i] = __builtin_amdgcn_s_memtime(); if ((i) == 0) t_[8] = __builtin_amdgcn_s_memrealtime(); if ((i) == 4) t_[9] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define S1_TR(i) do { } while (0)
 #endif
@@ -52,6 +54,13 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob
     const int pi = bpb_find_problem(bb, bid);
     const BpbConvS1Prob P = probs[pi];
     bid -= P.blk_begin;
+    // K split over two workgroups per tile (BpbS1Split): the blocks of the first halves come first in the grid, so every
+    // consumer's producer has been dispatched before it (the dispatcher hands out blocks in index order)
+    int khalf = 0;
+    if (P.split) {
+        khalf = bid >= P.n_mtiles * P.n_ntiles;
+        bid -= khalf * P.n_mtiles * P.n_ntiles;
+    }
     if (P.xr) {
         // XCD-aware tile map.  The dispatcher places block b on XCD b % 8 (observed, MI355X_MICROARCH.md; a wrong guess costs speed
         // only), each XCD has its own L2: with consecutive blocks on consecutive tiles every halo row shared by two neighbouring
@@ -61,6 +70,7 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob
         bid = f * q + min(f, r) + (bid >> 3);
     }
 
+    if (bid >= 0) S1_TR(10);                   // (descriptor arrived)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, l31 = lane & 31;
@@ -101,7 +111,8 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob
 
     constexpr int lvpp = KG == 1 ? 1 : KG == 2 ? 2 : 3;       // log2(CK / 4)
     const int npix = (1 << P.lTI) * HH * HWd;
-    const int nch = Cin / CK;                  // (CK divides Cin: host check)
+    const int nch = P.split ? (Cin / CK) >> 1 : Cin / CK;     // chunks of this workgroup (CK divides Cin, evenly with a split: host check)
+    const int cbase = khalf * nch;             // its first chunk
     // LDS map (16-byte slots): 2 x { halo [halo pixel][LD/4] padded to 256 slots, weights [tap][CK/4][NTC] padded }
     constexpr int qn = CK >> 2;
     const int spp = LD >> 2;
@@ -140,6 +151,7 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob
         hofs[k] = vo;
         __builtin_amdgcn_sched_barrier(0);   // one piece at a time keeps the register pressure flat
     }
+    if (hofs[0] != 1u) S1_TR(11);              // (halo offsets done)
 #pragma unroll
     for (int k = 0; k < DMA_WS; ++k) {
         unsigned vo = DMA_OOB;
@@ -189,11 +201,12 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob
         for (int mt = 0; mt < MT; ++mt) apix[t][mt] = pixoff[mt] + ((t / R) * HWd + (t % R)) * LD * 4;
     const int bstride = 2 * NTC * 16;          // bytes of one k-group of the weight tile
     S1_TR(1);
-    dma_issue(0, 0);
+    dma_issue(cbase * CK, 0);
+    S1_TR(12);                                 // (first chunk's DMA issued)
     for (int c = 0; c < nch; ++c) {
         if (!(S1_ABL & 2) || c == 0) __syncthreads();   // chunk c has landed (the barrier drains vmcnt) and the other buffer is free again
         if (c == 0) S1_TR(2);
-        if (c + 1 < nch && (!(S1_ABL & 1) || c == 0)) dma_issue((c + 1) * CK, (c + 1) & 1);
+        if (c + 1 < nch && (!(S1_ABL & 1) || c == 0)) dma_issue((cbase + c + 1) * CK, (c + 1) & 1);
         const char* lds = (const char*)smem;
         int bptr = (c & 1) * bufbytes + halo_reg * 16 + boff_lane;
         // Two-level summation: the MFMAs of one channel chunk (T * CK products per output) accumulate into `cacc`, the chunk sums
@@ -256,6 +269,68 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob
     }
 
     S1_TR(3);
+    if (P.split) {
+        // hand-over of the first half's accumulators (MI355X_MICROARCH.md, inter-workgroup visibility: the per-XCD L2s are not
+        // coherent with each other): write-through (sc1) 16-byte stores in register layout -> every wave drains its stores ->
+        // barrier -> relaxed agent-scope flag; the consumer polls relaxed, takes ONE agent acquire, reads with sc1 loads.
+        auto uniform = [](const void* p_) {
+            const unsigned long long u = (unsigned long long)p_;
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+            return (void*)(((unsigned long long)hi << 32) | lo);
+        };
+        const BpbS1Split* sp = P.split;
+        float* part = (float*)uniform(sp->part);
+        int* flags = (int*)uniform(sp->flags);
+        const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)part, 0, (int)sp->part_bytes, 0x00020000);
+        constexpr int SC1 = 16;
+        using b128_t = decltype(__builtin_amdgcn_raw_buffer_load_b128(rp, 0, 0, 0));    // (the builtins' own 16-byte vector type)
+        const unsigned pofs = (unsigned)((bid * (MT * NT * 4) * 256 + (int)threadIdx.x) * 16);
+        if (khalf == 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = {acc[mt][nt][q * 4 + 0], acc[mt][nt][q * 4 + 1], acc[mt][nt][q * 4 + 2], acc[mt][nt][q * 4 + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(b128_t, v), rp, (int)(pofs + (unsigned)(((mt * NT + nt) * 4 + q) * 4096)), 0, SC1);
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_store(flags + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef BPB_S1_TRACE
+            S1_TR(4);
+            if (g_s1_trace && (threadIdx.x & 63) == 0) {
+                unsigned long long* t = g_s1_trace + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+                t[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+                t[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+                t[7] = (unsigned long long)pi | 0x100;       // (first half of a K split)
+            }
+#endif
+            return;
+        }
+        if (threadIdx.x == 0) {
+            int spins = 0;          // (bounded: a lost hand-over must not hang the device; the time-out mark is checked by the host tools)
+            while (__hip_atomic_load(flags + bid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(8);
+            if (spins >= (1 << 20)) __hip_atomic_store(flags + P.n_mtiles * P.n_ntiles, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(flags + bid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    v[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, (int)(pofs + (unsigned)(((mt * NT + nt) * 4 + q) * 4096)), 0, SC1));
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[mt][nt][q * 4 + e] += v[q][e];
+            }
+    }
     // ---- epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31 (channel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
     // Stores (and the loads of the accumulate mode) go through a buffer descriptor; an invalid pixel adds 2^31 and an invalid
     // channel 2^30 to the 32-bit offset, so every invalid combination is dropped by the hardware (y is <= 1 GiB, host check).
@@ -424,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob
     __builtin_amdgcn_s_waitcnt(0);            // (vmcnt / lgkmcnt 0: the stores have been accepted)
     S1_TR(4);
     if (g_s1_trace && (threadIdx.x & 63) == 0) {
-        unsigned long long* t = g_s1_trace + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
+        unsigned long long* t = g_s1_trace + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
         t[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
         t[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
         t[7] = (unsigned long long)pi;
@@ -480,7 +555,7 @@ int bpb_conv_s1(const BpbConvS1Prob* d_probs, const BpbConvS1Prob* h_probs, int 
         const BpbConvS1Prob& p = h_probs[i];
         BPB_REQUIRE(p.nt == nt && p.mt_r == mt && p.R == R && p.CK == ck, "bpb_conv_s1: mixed kernel variants in one group");
         BPB_REQUIRE(p.Cin % 8 == 0 && p.Cout % 4 == 0, "bpb_conv_s1: Cin=%d must be a multiple of 8, Cout=%d of 4", p.Cin, p.Cout);
-        BPB_REQUIRE((p.CK == 8 || p.CK == 16 || p.CK == 32) && p.Cin % p.CK == 0 && p.LD == p.CK + 4,
+        BPB_REQUIRE((p.CK == 8 || p.CK == 16 || p.CK == 32) && p.Cin % p.CK == 0 && (p.LD == p.CK + 4 || p.LD == p.CK),
                     "bpb_conv_s1: bad channel chunk CK=%d (LD=%d) for Cin=%d", p.CK, p.LD, p.Cin);
         BPB_REQUIRE(p.lwn == 0 || p.lwn == 1, "bpb_conv_s1: lwn=%d", p.lwn);
         BPB_REQUIRE((1 << (p.lTI + p.lTH + p.lTW)) == (4 >> p.lwn) * mt * 32, "bpb_conv_s1: M tile / wave layout mismatch");
@@ -502,12 +577,14 @@ int bpb_conv_s1(const BpbConvS1Prob* d_probs, const BpbConvS1Prob* h_probs, int 
                         p.n_ntiles == bpb_cdiv(p.Cout, (32 * nt) << p.lwn),
                     "bpb_conv_s1: tile counts mismatch");
         BPB_REQUIRE(p.blk_begin == nblk, "bpb_conv_s1: blk_begin mismatch");
+        BPB_REQUIRE(p.split == nullptr || ((p.Cin / p.CK) % 2 == 0 && (double)p.n_mtiles * p.n_ntiles * mt * nt * 16384.0 < 2147483648.0),
+                    "bpb_conv_s1: a K split needs an even number of channel chunks (Cin=%d, CK=%d) and < 2 GiB of hand-over space", p.Cin, p.CK);
         const int npix = (1 << p.lTI) * p.HH * p.HW;
         const int halo_pad = (npix * (p.LD / 4) + 255) & ~255;
         const int b_pad = (R * R * (p.CK / 4) * ((nt * 32) << p.lwn) + 255) & ~255;
         BPB_REQUIRE(halo_pad <= 12 * 256 && b_pad <= 12 * 256, "bpb_conv_s1: more than 12 DMA pieces per thread (halo %d, weights %d slots)",
                     halo_pad, b_pad);
-        nblk += p.n_mtiles * p.n_ntiles;
+        nblk += p.n_mtiles * p.n_ntiles * (p.split ? 2 : 1);
         const int l = conv_s1_lds_bytes(p);
         lds = l > lds ? l : lds;
     }

@@ -167,6 +167,7 @@ class Net:
         self.cur_region = 0        # 0 outside fork..join, otherwise the ordinal of the enclosing fork
         self._nregions = 0
         self.node_regions = []
+        self.split_flags = []      # (flags tensor, tiles) of every K-split conv_s1 problem
         self.debug_convs = []      # (ConvProb | ConvS1Prob, x, packed w, y) -- lets the CPU tests emulate the descriptors
         self.debug_wgrads = []     # (WgradProb, ConvNode)
         self.debug_wgrad1x1 = []   # (Wgrad1x1Prob, ConvNode)
@@ -386,6 +387,14 @@ class Net:
         p.xr = 1 if os.environ.get('BPB_XCD_MAP', '1') != '0' else 0
         p.lTI, p.lTH, p.lTW = _log2(ti), _log2(th), _log2(tw)
         p.HH, p.HW, p.CK, p.LD = hh, hw, ck, ck + 4
+        # The 4-float padding of a halo pixel keeps the A-fragment reads free of bank conflicts.  A grouped launch allocates the
+        # LDS of its largest problem for every workgroup: where the padding alone pushes a tile over a quarter of the CU's LDS
+        # (the 8x4 maps of the deepest HRNet branch: four whole images per tile, 240 halo pixels -> 41.5 KB), the launch would run
+        # three instead of four workgroups per CU (tools/s1_trace.py) -- that problem stages its halo unpadded.
+        quarter = 160 * 1024 // 4
+        lds_of = lambda ld_: 2 * ((ti * hh * hw * (ld_ // 4) + 3) // 4 * 4 + t * (ck // 4) * ntc) * 16
+        if lds_of(ck + 4) > quarter >= lds_of(ck) and os.environ.get('BPB_S1_NOPAD', '1') != '0':
+            p.LD = ck
         p.tiles_a, p.tiles_b = _cdiv(h, th), _cdiv(w, tw)
         p.n_mtiles = _cdiv(n, ti) * p.tiles_a * p.tiles_b
         p.n_ntiles = _cdiv(cout, ntc)
@@ -867,6 +876,8 @@ class Net:
                 continue
             g = sorted(g, key=lambda r_: -r_.work)          # stable: heaviest workgroups first in the grid
             ctype = type(g[0].desc)
+            if ctype is ConvS1Prob:
+                self._split_deep_chains(g)
             host = (ctype * len(g))()
             blk = 0
             for q, r_ in enumerate(g):
@@ -882,6 +893,35 @@ class Net:
             meta.append({'label': label, 'flops': sum(r_.flops for r_ in g), 'bytes': sum(r_.bytes for r_ in g), 'n': len(g)})
         self.keep.append(arr)
         return arr, len(groups), meta
+
+    def _split_deep_chains(self, g):
+        """K split of the deepest problems of a grouped conv_s1 launch (BpbS1Split, csrc/conv_s1.hip).  A launch lasts as long as
+        its longest chain of channel chunks: the 256-channel branch of an HRNet module step has 32 chunks per wave against 4 of
+        the 32-channel one and runs for the whole launch while the rest of the chip drains (tools/s1_trace.py: 216 k cycles
+        against a slot-throughput bound of 158 k).  Problems with >= BPB_S1_SPLIT_RATIO (default 8, 0: never) times the
+        lightest problem's MFMAs per wave take two workgroups per tile."""
+        ratio = float(os.environ.get('BPB_S1_SPLIT_RATIO', '8'))
+        lightest = min(r_.work for r_ in g)
+        for r_ in g:
+            d = r_.desc
+            ntiles = d.n_mtiles * d.n_ntiles
+            if d.split:                                   # (a record frozen into a second plan keeps its split)
+                r_.blocks = 2 * ntiles
+                continue
+            if ratio <= 0 or len(g) < 2 or r_.work < ratio * lightest or (d.Cin // d.CK) % 2 or d.Cin // d.CK < 8:
+                continue
+            part = torch.empty(ntiles * d.mt_r * d.nt * 4 * 256 * 4, device=self.device, dtype=torch.float32)
+            flags = torch.zeros(ntiles + 1, device=self.device, dtype=torch.int32)
+            sp = nv.S1Split()
+            sp.part, sp.flags, sp.part_bytes = part.data_ptr(), flags.data_ptr(), part.numel() * 4
+            d.split = self._dev_struct(sp).data_ptr()
+            self.keep += [part, flags]
+            self.split_flags.append((flags, ntiles))
+            r_.blocks = 2 * ntiles
+
+    def split_timeouts(self):
+        """Number of K-split problems whose consumer workgroups ever gave up waiting for their producer (must be 0; host sync)."""
+        return sum(int(f_[n_].item()) for f_, n_ in self.split_flags)
 
     # ------------------------------------------------------------------ backward plan
     def _flush_reduce(self, bwd):

@@ -29,8 +29,12 @@ class S1BnBwd(C.Structure):
     _fields_ = [('out', c_fp), ('src', c_fp), ('mean', c_fp), ('invstd', c_fp)]
 
 
+class S1Split(C.Structure):
+    _fields_ = [('part', c_fp), ('flags', c_fp), ('part_bytes', C.c_uint), ('pad_', C.c_int)]
+
+
 class ConvS1Prob(C.Structure):
-    _fields_ = [('x', c_fp), ('w', c_fp), ('y', c_fp), ('bias', c_fp), ('stats', c_fp), ('res', c_fp), ('bnb', c_fp)] + [
+    _fields_ = [('x', c_fp), ('w', c_fp), ('y', c_fp), ('bias', c_fp), ('stats', c_fp), ('res', c_fp), ('bnb', c_fp), ('split', c_fp)] + [
         (n, C.c_int) for n in (
             'N', 'H', 'W', 'Cin', 'Cout', 'R', 'lTI', 'lTH', 'lTW', 'HH', 'HW', 'CK', 'LD', 'tiles_a', 'tiles_b', 'n_mtiles',
             'n_ntiles', 'blk_begin', 'lwn', 'mt_r', 'nt', 'accumulate', 'relu', 'wflip')] + [

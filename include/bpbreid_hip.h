@@ -96,6 +96,17 @@ typedef struct BpbS1BnBwd {
     const float* invstd;    // [Cout]
 } BpbS1BnBwd;
 
+/* K split of one problem of a grouped bpb_conv_s1 launch over two workgroups per tile (the deepest HRNet branch has 32 channel
+ * chunks per wave against 4 of the widest one, and a grouped launch lasts as long as its longest chain): the problem takes
+ * 2 * n_mtiles * n_ntiles blocks, block b < n computes the first half of the channel chunks of tile b and hands its
+ * accumulators over through `part`, block n + b computes the second half, adds them and runs the epilogue. */
+typedef struct BpbS1Split {
+    float* part;            // [n_mtiles * n_ntiles][mt_r * nt * 4][256][4] accumulators of the first half (register layout)
+    int* flags;             // [n_mtiles * n_ntiles + 1] zero before the first launch; hand-off flags, [n] = 1 after a timed-out wait
+    unsigned part_bytes;
+    int pad_;
+} BpbS1Split;
+
 /* Stride-1 convolution problem of the lean hot-path kernel (csrc/conv_s1.hip): R x R filter (R = 1 or 3), stride 1, padding
  * R/2, NHWC, y = conv(x, W) [+ bias][ReLU] or y += ... (data gradient of a convolution read by several consumers).
  *   forward   torchreid/models/hrnet.py:61-64,72,75,104-110,223 ; torchreid/models/resnet.py:31-49,119-127
@@ -108,11 +119,13 @@ typedef struct BpbConvS1Prob {
     double* stats;          // optional [n_mtiles][2][Cout] per-tile (sum, sumsq) partials for BatchNorm
     const float* res;       // optional [N][H][W][Cout]: y = act(conv + bias + res) -- the residual add of a block in the eval plan
     const BpbS1BnBwd* bnb;  // optional (device pointer, needs `stats`): `stats` receives the BatchNorm-backward partials instead
+    const BpbS1Split* split;   // optional (device pointer): two workgroups per tile, each half of the channel chunks
     int N, H, W, Cin, Cout; // Cin multiple of 8, Cout multiple of 4
     int R;                  // 1 or 3
     int lTI, lTH, lTW;      // M tile = 2^lTI images x 2^lTH rows x 2^lTW columns = (4 >> lwn) * mt_r * 32 pixels
     int HH, HW;             // staged input extent of a tile: (TH - 1) * S + R, (TW - 1) * S + R
-    int CK, LD;             // channel chunk per pipeline stage (8, 16, 32) and LDS pitch of a halo pixel (CK + 4 floats)
+    int CK, LD;             // channel chunk per pipeline stage (8, 16, 32) and LDS pitch of a halo pixel: CK + 4 floats (conflict-free
+                            // fragment reads), or CK where the padding alone would cost the launch a workgroup per CU
     int tiles_a, tiles_b, n_mtiles, n_ntiles;
     int blk_begin;          // first blockIdx of this problem inside a grouped launch
     int lwn, mt_r, nt;      // wave tile: 2^lwn waves along channels, mt_r 32-pixel and nt 32-channel sub-tiles per wave

@@ -112,7 +112,7 @@ def run_conv_s1(p, x, wpk, y, bias=None, res=None, bn=None):
     mt_pix = ti_n * th_n * tw_n
     ntc = (32 * p.nt) << p.lwn
     assert mt_pix == (4 >> p.lwn) * p.mt_r * 32 and p.n_ntiles == -(-p.Cout // ntc)
-    assert p.HH == (th_n - 1) * p.S + R and p.HW == (tw_n - 1) * p.S + R and p.LD == p.CK + 4
+    assert p.HH == (th_n - 1) * p.S + R and p.HW == (tw_n - 1) * p.S + R and p.LD in (p.CK, p.CK + 4)
     cin, cout, ld, ck = p.Cin, p.Cout, p.LD, p.CK
     cin4, qn, spp = cin // 4, ck // 4, ld // 4
     npix = ti_n * p.HH * p.HW

@@ -172,6 +172,60 @@ def test_conv_forward_backward(case, s1, tile=None, tpb=None, dma=True, ck=None)
         assert rel_err(nchw(xa.grad), xr.grad) < 1e-4, 'dgrad'
 
 
+@pytest.mark.parametrize('ratio', ['2', '8'])
+def test_conv_s1_k_split_across_workgroups(ratio, monkeypatch):
+    """A grouped launch whose deep problems take two workgroups per tile (BpbS1Split: first half of the channel chunks ->
+    hand-over through memory -> second half + epilogue), forward with BatchNorm partials, data and weight gradients, twice (the
+    hand-over flags re-arm themselves)."""
+    monkeypatch.setenv('BPB_S1_SPLIT_RATIO', ratio)
+    g = torch.Generator().manual_seed(77)
+    shapes = [(24, 12, 16, 16), (12, 6, 64, 64), (9, 5, 128, 32), (6, 3, 256, 256)]     # (H, W, Cin, Cout)
+    n = 6
+    net = Net(DEV)
+    net.fork(len(shapes))
+    items = []
+    for i, (h, w, cin, cout) in enumerate(shapes):
+        net.set_slot(i)
+        x = torch.randn(n, cin, h, w, generator=g)
+        wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+        xa = Act(net, n, h, w, cin)
+        xa.needs_grad = True
+        xa.buf.copy_(nhwc(x))
+        wp = wt.to(DEV)
+        wp.grad = torch.zeros_like(wp)
+        gamma, beta = torch.ones(cout, device=DEV), torch.zeros(cout, device=DEV)
+        gamma.grad, beta.grad = torch.zeros_like(gamma), torch.zeros_like(beta)
+        node = net.conv(xa, wp, 1, 1, bn=(gamma, beta, torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV)))
+        out = net.fuse([(node, 0)], relu=True)
+        items.append((x, wt, xa, wp, node, out))
+    net.set_slot(0)
+    net.join(len(shapes))
+    net.finalize(train_backward=True)
+    probs = [p for p, *_ in net.debug_convs if isinstance(p, nv.ConvS1Prob)]
+    nsplit = sum(1 for p in probs if p.split)
+    assert nsplit >= (4 if ratio == '2' else 2), 'no problem was split (forward + data gradient)'
+    grads = [torch.randn(it[5].buf.shape, generator=g) for it in items]
+    for rep in range(2):
+        for it in items:
+            it[3].grad.zero_()
+        net.run(net.plan_train)
+        for it, gr in zip(items, grads):
+            it[5].grad.copy_(gr)
+        net.run(net.plan_bwd)
+        torch.cuda.synchronize()
+        assert net.split_timeouts() == 0
+        for (x, wt, xa, wp, node, out), gr in zip(items, grads):
+            xr = x.double().requires_grad_(True)
+            wr = wt.double().requires_grad_(True)
+            yr = F.conv2d(xr, wr, padding=1)
+            assert rel_err(nchw(node.y.buf), yr.detach()) < 2e-5, 'conv forward (pass %d)' % rep
+            o2 = F.relu(F.batch_norm(yr, None, None, training=True, eps=1e-5))
+            assert rel_err(nchw(out.buf), o2.detach()) < 5e-5, 'bn apply'
+            o2.backward(nchw(gr).double())
+            assert rel_err(wp.grad, wr.grad) < 1e-4, 'wgrad'
+            assert rel_err(nchw(xa.grad), xr.grad) < 1e-4, 'dgrad'
+
+
 def _module_parity(pmod, omod, in_shapes, train_steps=1):
     """Emit a product module into a plan, run fwd/bwd on the GPU, compare with the oracle module in fp64 on the CPU."""
     Cm.fill_state_dict_(omod)

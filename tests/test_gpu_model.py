@@ -18,6 +18,7 @@ import common as Cm                                            # noqa: E402
 from bpbreid_amd.model import bpbreid                         # noqa: E402
 from bpbreid_amd.engine import ImagePartBasedEngine           # noqa: E402
 from bpbreid_amd.optim import FusedAdam                       # noqa: E402
+from bpbreid_amd import native as nv                          # noqa: E402
 
 DEV = torch.device('cuda', 0)
 
@@ -413,9 +414,17 @@ def test_repeated_steps_are_bit_identical_and_grouping_or_kernel_choice_do_not_c
     assert net.grouped and net.use_s1 and any(len(g) > 1 for g in net.plan_groups['bwd'])
     for r in base[1:]:
         assert torch.equal(r[0], base[0][0]) and torch.equal(r[1], base[0][1]) and torch.equal(r[2], base[0][2])
+    # the K split of the deepest problems of a grouped launch (two workgroups per tile, BpbS1Split) sums the two halves of the
+    # channel chunks separately: bit-identical from run to run (above), equal to the unsplit launch up to fp32 summation order
+    assert any(p.split for p, *_ in net.debug_convs if isinstance(p, nv.ConvS1Prob)) and net.split_timeouts() == 0
+    nosplit, net0 = run(1, BPB_S1_SPLIT_RATIO='0')
+    assert not any(p.split for p, *_ in net0.debug_convs if isinstance(p, nv.ConvS1Prob))
+    assert abs(nosplit[0][3] - base[0][3]) < 1e-5 * abs(base[0][3])
+    assert (nosplit[0][1] - base[0][1]).abs().max() < 1e-4 * base[0][1].abs().max()
+    assert torch.nn.functional.cosine_similarity(nosplit[0][2], base[0][2], dim=0) > 0.999
     single, net1 = run(1, BPB_GROUPED='0')
     assert not net1.grouped and all(len(g) == 1 for g in net1.plan_groups['bwd'])
-    assert torch.equal(single[0][0], base[0][0]) and torch.equal(single[0][1], base[0][1]) and torch.equal(single[0][2], base[0][2])
+    assert torch.equal(single[0][0], nosplit[0][0]) and torch.equal(single[0][1], nosplit[0][1]) and torch.equal(single[0][2], nosplit[0][2])
     general, net2 = run(1, BPB_CONV_S1='0')
     assert not net2.use_s1
     assert abs(general[0][3] - base[0][3]) < 1e-5 * abs(base[0][3])
@@ -426,10 +435,10 @@ def test_repeated_steps_are_bit_identical_and_grouping_or_kernel_choice_do_not_c
     # BatchNorm-backward partials from the data-gradient epilogue vs the separate reduce pass: the same forward bit for bit,
     # the same gradient up to the summation order of the per-channel sums
     assert any('+bn_bwd_partials' in r.label for r in net.bwd)
-    sep, net3 = run(1, BPB_DGRAD_BN='0')
+    sep, net3 = run(1, BPB_DGRAD_BN='0', BPB_S1_SPLIT_RATIO='0')
     assert not any('+bn_bwd_partials' in r.label for r in net3.bwd)
-    assert torch.equal(sep[0][0], base[0][0]) and torch.equal(sep[0][1], base[0][1]) and sep[0][3] == base[0][3]
-    assert (sep[0][2] - base[0][2]).abs().max() <= 2e-5 * base[0][2].abs().max()
+    assert torch.equal(sep[0][0], nosplit[0][0]) and torch.equal(sep[0][1], nosplit[0][1]) and sep[0][3] == nosplit[0][3]
+    assert (sep[0][2] - nosplit[0][2]).abs().max() <= 2e-5 * nosplit[0][2].abs().max()
 
 
 @pytest.mark.parametrize('cfg', [('resnet50', 5, 256, 128), ('hrnet32', 5, 256, 128), ('hrnet48', 8, 384, 128)],

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_the_c_side():
     # sizes are asserted against values printed by the compiler (static_asserts live in csrc/abi_check.cpp)
     assert C.sizeof(nv.ConvProb) == 5 * 8 + 49 * 4 + 4 + 8 + 8     # padding before the bnf pointer, relu + tail padding
-    assert C.sizeof(nv.ConvS1Prob) == 7 * 8 + 24 * 4 + 9 * 4 + 4 * 4 + 4    # + tail padding
+    assert C.sizeof(nv.ConvS1Prob) == 8 * 8 + 24 * 4 + 9 * 4 + 4 * 4 + 4    # + tail padding
     assert C.sizeof(nv.WgradProb) == 3 * 8 + 27 * 4 + 5 * 4 + 4 + 4    # + ntw + tail padding
     assert C.sizeof(nv.PlanOp) == 4 + 11 * 4 + 4 * 4 + 2 * 8 + 12 * 8
 
@@ -46,7 +46,7 @@ def test_ctypes_mirrors_have_the_c_layout(tmp_path):
     pairs = {'BpbConvProb': nv.ConvProb, 'BpbConvS1Prob': nv.ConvS1Prob, 'BpbS1BnBwd': nv.S1BnBwd, 'BpbBnFinDesc': nv.BnFinDesc, 'BpbBnBwdFinDesc': nv.BnBwdFinDesc,
              'BpbWgradReduceDesc': nv.WgradReduceDesc, 'BpbWgradProb': nv.WgradProb, 'BpbPackProb': nv.PackProb, 'BpbFuseArgs': nv.FuseArgs,
              'BpbTermBwdArgs': nv.TermBwdArgs, 'BpbBilinearArgs': nv.BilinearArgs, 'BpbBilinearBwdDesc': nv.BilinearBwdDesc, 'BpbWgrad1x1Prob': nv.Wgrad1x1Prob, 'BpbGemmProb': nv.GemmProb, 'BpbBnFinalizeArgs': nv.BnFinalizeArgs,
-             'BpbBnEvalDesc': nv.BnEvalDesc, 'BpbPlanOp': nv.PlanOp, 'BpbHeadBranch': nv.HeadBranch}
+             'BpbBnEvalDesc': nv.BnEvalDesc, 'BpbPlanOp': nv.PlanOp, 'BpbHeadBranch': nv.HeadBranch, 'BpbS1Split': nv.S1Split}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "bpbreid_hip.h"', 'int main(void) {']
     for cname, cls in pairs.items():
         lines.append('printf("%s.sizeof %%zu\\n", sizeof(%s));' % (cname, cname))

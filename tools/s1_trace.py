@@ -66,46 +66,53 @@ for _ in range(20):
 e.record()
 torch.cuda.synchronize()
 us = s.elapsed_time(e) * 1e3 / 20
-buf = torch.zeros(nblk * 4 * 8, dtype=torch.int64, device=dev)
+nblk_grid = sum(p.n_mtiles * p.n_ntiles * (2 if p.split else 1) for p in probs)
+buf = torch.zeros(nblk_grid * 4 * 16, dtype=torch.int64, device=dev)
 lib = nv.lib()
 lib.bpb_conv_s1_set_trace.argtypes = [C.c_void_p]
 nv.check(lib.bpb_conv_s1_set_trace(buf.data_ptr()))
 nv.call('bpb_plan_run', C.cast(one, C.c_void_p), 1, nv.stream())     # a traced launch right behind another one, like in the plan
 nv.call('bpb_plan_run', C.cast(one, C.c_void_p), 1, nv.stream())
 torch.cuda.synchronize()
-t = buf.cpu().numpy().reshape(nblk * 4, 8)
+t = buf.cpu().numpy().reshape(nblk_grid * 4, 16)
 nv.check(lib.bpb_conv_s1_set_trace(None))
-t0, t1, t2, t3, t4, hw, xcc, pi = [t[:, i].astype(np.int64) for i in range(8)]
-# every XCD has its own s_memtime base: times are taken relative to the first wave start ON THE SAME XCD (the dispatcher starts
-# all XCDs within a fraction of a microsecond of each other)
-xid = xcc & 15
-for x_ in np.unique(xid):
-    m_ = xid == x_
-    b_ = t0[m_].min()
-    for a_ in (t0, t1, t2, t3, t4):
-        a_[m_] -= b_
-base = 0
-span = t4.max() - base
-print('waves per XCD:', {int(x_): int((xid == x_).sum()) for x_ in np.unique(xid)}, ' end of the last wave per XCD:',
-      {int(x_): int(t4[xid == x_].max()) for x_ in np.unique(xid)})
-print('%s: %d workgroups, %.1f GFLOP, %.1f us per launch (%.1f TF) untraced; traced launch spans %d ticks'
-      % (what, nblk, flops * 1e-9, us, flops / us * 1e-6, span))
-print('tile/ck per problem:', [(p.mt_r, p.lwn, p.nt, p.CK, p.n_mtiles * p.n_ntiles) for p in probs])
-ticks_per_us = span / us          # (the traced launch is a little slower than the untraced average: an estimate)
-print('~%.0f ticks per us if the traced launch took the untraced time' % ticks_per_us)
+t0, t1, t2, t3, t4, hw, xcc, pi_raw, r0, r4, t10, t11, t12 = [t[:, i].astype(np.int64) for i in range(13)]
+pi = pi_raw & 0xff
+first_half = (pi_raw & 0x100) != 0
+# s_memtime (t0..t4) counts shader cycles from a base of its own per CU: only differences within a wave are used.  The launch
+# timeline comes from s_memrealtime (r0 entry, r4 exit: the chip-wide 100 MHz clock), converted to shader cycles per wave.
+CYC = 2400.0 / 100.0                      # nominal shader cycles per realtime tick (tools/mfma_peak.py: 2.39 GHz sustained)
+start = (r0 - r0.min()) * CYC
+end = (r4 - r0.min()) * CYC
+span = end.max()
+print('%s: %d workgroups, %.1f GFLOP, %.1f us per launch (%.1f TF) untraced; the traced launch spans %.1f us from the first wave entry to the last exit'
+      % (what, nblk_grid, flops * 1e-9, us, flops / us * 1e-6, span / 2400.0))
+print('tile/ck/blocks per problem:', [(p.mt_r, p.lwn, p.nt, p.CK, p.n_mtiles * p.n_ntiles * (2 if p.split else 1)) for p in probs])
 pc = lambda a, q: np.percentile(a, q)
 order = sorted(range(len(probs)), key=lambda k_: -(probs[k_].R * probs[k_].R * probs[k_].Cin * probs[k_].mt_r * probs[k_].nt))    # grid order: heaviest first
 probs = [probs[k_] for k_ in order]
-print('problem   waves   start(p50,p95)   end(p50,p95,max)   prologue   1st-chunk wait   mfma loop   epilogue   lifetime   (ticks, medians; [p10..p90])')
+print('problem   waves   entry us (p5,p50,p95)   exit us (p50,p95,max)   prologue   1st-chunk wait   mfma loop   epilogue   lifetime   (shader cycles, medians; [p10..p90])')
 for k in sorted(set(pi.tolist())):
-    m = pi == k
-    row = ['%4d(C%d)' % (k, probs[k].Cin), '%6d' % m.sum(), '%7d %7d' % (pc(t0[m] - base, 50), pc(t0[m] - base, 95)),
-           '%7d %7d %7d' % (pc(t4[m], 50), pc(t4[m], 95), t4[m].max())]
-    for a, b in ((t0, t1), (t1, t2), (t2, t3), (t3, t4), (t0, t4)):
+    for fh in (True, False):
+        m = (pi == k) & (first_half == fh)
+        if not m.any():
+            continue
+        row = ['%4d(C%d%s)' % (k, probs[k].Cin, ' 1st half' if fh else ''), '%6d' % m.sum(),
+               '%6.1f %6.1f %6.1f' % tuple(pc(start[m], q) / 2400.0 for q in (5, 50, 95)),
+               '%6.1f %6.1f %6.1f' % (pc(end[m], 50) / 2400.0, pc(end[m], 95) / 2400.0, end[m].max() / 2400.0)]
+        for a, b in ((t0, t1), (t1, t2), (t2, t3), (t3, t4), (t0, t4)):
+            d = (b - a)[m]
+            row.append('%6d [%d..%d]' % (pc(d, 50), pc(d, 10), pc(d, 90)))
+        print('  '.join(row))
+print('prologue in detail (medians [p10..p90]): entry -> descriptor in SGPRs -> halo DMA offsets -> all offsets -> first DMA issued')
+for k in sorted(set(pi.tolist())):
+    m = (pi == k) & ~first_half
+    row = ['%4d(C%d)' % (k, probs[k].Cin)]
+    for a, b in ((t0, t10), (t10, t11), (t11, t1), (t1, t12)):
         d = (b - a)[m]
         row.append('%6d [%d..%d]' % (pc(d, 50), pc(d, 10), pc(d, 90)))
     print('  '.join(row))
-# per-SIMD concurrency of the MFMA loops
+# per-SIMD residency over the launch (realtime timeline)
 simd = (hw >> 4) & 3
 cu = (hw >> 8) & 15
 sh = (hw >> 12) & 1
@@ -114,35 +121,31 @@ key = ((xcc & 15) << 12) | (se << 8) | (sh << 7) | (cu << 2) | simd
 keys = np.unique(key)
 print('%d distinct SIMDs hosted waves (1024 on the chip)' % len(keys))
 grid = 400
+edges = np.linspace(0, span, grid + 1)
 occ_any = np.zeros(grid)
 occ_mfma = np.zeros(grid)
-edges = np.linspace(0, span, grid + 1)
-busy_frac, mfma_frac, nw = [], [], []
-for kk in keys:
-    m = key == kk
-    nw.append(m.sum())
-    a_any = np.zeros(grid)
-    a_m = np.zeros(grid)
-    for w0, w2, w3, w4 in zip(t0[m] - base, t2[m] - base, t3[m] - base, t4[m] - base):
-        i0, i4 = np.searchsorted(edges, [w0, w4])
-        a_any[max(0, i0 - 1):i4] += 1
-        i2, i3 = np.searchsorted(edges, [w2, w3])
-        a_m[max(0, i2 - 1):i3] += 1
-    occ_any += a_any
-    occ_mfma += a_m
-    busy_frac.append((a_any > 0).mean())
-    mfma_frac.append((a_m > 0).mean())
+# MFMA-loop interval of a wave on the realtime axis: entry + (t2 - t0) .. entry + (t3 - t0)
+m2, m3 = start + (t2 - t0), start + (t3 - t0)
+i0 = np.clip(np.searchsorted(edges, start) - 1, 0, grid)
+i4 = np.searchsorted(edges, end)
+j2 = np.clip(np.searchsorted(edges, m2) - 1, 0, grid)
+j3 = np.searchsorted(edges, m3)
+for a, b, c_, d_ in zip(i0, i4, j2, j3):
+    occ_any[a:b] += 1
+    if d_ > c_ and True:
+        occ_mfma[c_:d_] += 1
+nw = [int((key == kk).sum()) for kk in keys]
 print('waves per SIMD over the launch: min %d median %d max %d' % (min(nw), np.median(nw), max(nw)))
-print('fraction of the launch span with >= 1 resident wave per SIMD: mean %.3f ; with >= 1 wave inside its MFMA loop: mean %.3f (min %.3f)'
-      % (np.mean(busy_frac), np.mean(mfma_frac), np.min(mfma_frac)))
-print('timeline (launch span in 20 slices): mean resident waves per SIMD | mean waves inside the MFMA loop per SIMD')
+print('timeline (launch span in 20 slices of %.1f us): mean resident waves per SIMD | mean waves inside their MFMA loop per SIMD' % (span / 2400.0 / 20))
 for q in range(20):
     sl = slice(q * grid // 20, (q + 1) * grid // 20)
-    print('  %3d%%  %.2f  %.2f' % (q * 5, occ_any[sl].mean() / len(keys), occ_mfma[sl].mean() / len(keys)))
+    print('  %3d%%  %.2f  %.2f' % (q * 5, occ_any[sl].mean() / 1024.0, occ_mfma[sl].mean() / 1024.0))
+tot_life = float((end - start).sum())
+print('sum of wave lifetimes / (1024 SIMDs x span) = %.2f resident waves per SIMD on average' % (tot_life / (1024.0 * span)))
 # the MFMA loop's own efficiency: MFMAs * 64 cycles / loop duration, per problem
 for k, p in enumerate(probs):
-    m = pi == k
-    mf = p.R * p.R * p.Cin // 2 * p.mt_r * p.nt
+    m = (pi == k) & ~first_half
+    mf = p.R * p.R * p.Cin // 2 * p.mt_r * p.nt // (2 if p.split else 1)
     d = (t3 - t2)[m]
-    print('problem %d: %d MFMAs per wave = %d pipe cycles; median loop %d ticks -> one wave holds %.2f of its SIMD pipe while in the loop'
+    print('problem %d: %d MFMAs per wave = %d pipe cycles; median loop %d cycles -> one wave holds %.2f of its SIMD pipe while in the loop'
           % (k, mf, mf * 64, pc(d, 50), mf * 64 / pc(d, 50)))
