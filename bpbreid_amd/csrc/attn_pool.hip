@@ -15,13 +15,31 @@
 
 #define BPB_HEAD_MAXJ 12
 
+// The head on the branch outputs of HRNet (csrc/head_lowres.hip) runs the same small pass over four tensors of different
+// resolution and width: one launch takes up to 8 of them (blockIdx.z = branch, parameters by value, blocks beyond a branch's own
+// grid return at once) instead of four launches of 8-23 us that mostly wait for each other's tail.
+#define BPB_HEAD_MAXB 8
+struct BpbHeadMulti {
+    const float* x[BPB_HEAD_MAXB];      // the branch tensors [N][HW_b][C_b]  (pool_finalize: the pooling partials)
+    const float* a[BPB_HEAD_MAXB];      // second operand: weight rows (pixel_dots) / masks (masked_pool)
+    float* out[BPB_HEAD_MAXB];
+    int HW[BPB_HEAD_MAXB], C[BPB_HEAD_MAXB];
+    int p0[BPB_HEAD_MAXB];              // pixels per block (pixel_dots) / LDS pixel slots (masked_pool)
+    int p1[BPB_HEAD_MAXB];              // blocks along x of this branch (masked_pool, pool_finalize: nchunks)
+    int c0[BPB_HEAD_MAXB];              // first channel of the branch inside the concatenated width (pool_finalize)
+};
+
 // ---------------------------------------------------------------------------------------------
 template <int J>
-__global__ __launch_bounds__(256) void bpb_pixel_dots_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                             long w_image_stride, long w_row_stride, const float* __restrict__ bias,
-                                                             float* __restrict__ out, int HW, int C, int pix_per_block)
+__global__ __launch_bounds__(256) void bpb_pixel_dots_kernel(BpbHeadMulti A, long w_image_stride, long w_row_stride, const float* __restrict__ bias)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // w rows [J][C]
+    const int br = blockIdx.z;
+    const float* __restrict__ x = A.x[br];
+    const float* __restrict__ w = A.a[br];
+    float* __restrict__ out = A.out[br];
+    const int HW = A.HW[br], C = A.C[br], pix_per_block = A.p0[br];
+    if ((int)blockIdx.x * pix_per_block >= HW) return;
     const int n = blockIdx.y;
     const float* wn = w + (long)n * w_image_stride;
     for (int i = threadIdx.x; i < J * (C >> 2); i += 256) {
@@ -100,12 +118,17 @@ __host__ __device__ __forceinline__ int head_slots(int HW, int C, int nchunks)
 }
 
 template <int J>
-__global__ __launch_bounds__(256) void bpb_masked_pool_kernel(const float* __restrict__ x, const float* __restrict__ m,
-                                                              float* __restrict__ part, int HW, int C, int slots)
+__global__ __launch_bounds__(256) void bpb_masked_pool_kernel(BpbHeadMulti A)
 {
     constexpr int JP = (J + 3) & ~3;                              // mask rows padded to whole float4s
     extern __shared__ __attribute__((aligned(16))) float smem[];   // masks [slots][JP], then the row partials
-    const int n = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+    const int br = blockIdx.z;
+    const float* __restrict__ x = A.x[br];
+    const float* __restrict__ m = A.a[br];
+    float* __restrict__ part = A.out[br];
+    const int HW = A.HW[br], C = A.C[br], slots = A.p0[br];
+    const int n = blockIdx.y, chunk = blockIdx.x, nchunks = A.p1[br];
+    if (chunk >= nchunks) return;
     const int c4 = C >> 2;
     const int tx = c4 >= 256 ? 256 : c4, rows = 256 / tx;
     const int G = rows * HEAD_U;
@@ -369,11 +392,14 @@ __global__ __launch_bounds__(256) void bpb_visibility_kernel(const float* __rest
 // GlobalAveragePoolingHead of bpbreid.py:432-441, :485-486 -- the mean of mask * feature over ALL pixels).  Also saves
 // zinv[n][j] = norm_j for the backward; a NEGATIVE sign marks "the norm does not depend on the mask" (active clamp, or gap):
 // the backward then drops the -S/Z^2 term.  Deterministic fixed-order sum.
-__global__ __launch_bounds__(256) void bpb_pool_finalize_kernel(const float* __restrict__ part, const float* __restrict__ pm,
+__global__ __launch_bounds__(256) void bpb_pool_finalize_kernel(BpbHeadMulti A, const float* __restrict__ pm,
                                                                 float* __restrict__ pooled, float* __restrict__ zinv,
-                                                                int nchunks, int J, int HW, int C, int parts_gap, int c0, int Ct)
+                                                                int J, int HW, int parts_gap, int Ct)
 {
     __shared__ float red[256];
+    const int br = blockIdx.z;
+    const float* __restrict__ part = A.x[br];
+    const int nchunks = A.p1[br], C = A.C[br], c0 = A.c0[br];
     const int n = blockIdx.y, j = blockIdx.x;
     float norm;
     if (j < 3 || parts_gap) {
@@ -389,7 +415,7 @@ __global__ __launch_bounds__(256) void bpb_pool_finalize_kernel(const float* __r
         }
         norm = 1.f / fmaxf(red[0], 1e-6f);
     }
-    if (threadIdx.x == 0) zinv[(long)n * J + j] = (j >= 3 && (norm >= 1e6f || parts_gap)) ? -norm : norm;
+    if (threadIdx.x == 0 && br == 0) zinv[(long)n * J + j] = (j >= 3 && (norm >= 1e6f || parts_gap)) ? -norm : norm;
     for (int c = threadIdx.x; c < C; c += 256) {
         float s = 0.f;
         for (int q = 0; q < nchunks; ++q) s += part[(((long)n * nchunks + q) * J + j) * C + c];
@@ -721,20 +747,66 @@ int bpb_head_init(void)
     return 0;
 }
 
-// out[n][p][j] = sum_c w[n*w_image_stride + j*w_row_stride + c] x[n][p][c] + bias[j]
+// out_b[n][p][j] = sum_c w_b[n*w_image_stride + j*w_row_stride + c] x_b[n][p][c] + bias[j]   for nb <= 8 tensors x_b [N][HW_b][C_b]
+int bpb_pixel_dots_multi(const float* const* x, const float* const* w, float* const* out, const int* HW, const int* C, int nb,
+                         long w_image_stride, long w_row_stride, const float* bias, int N, int J, hipStream_t stream)
+{
+    BPB_REQUIRE(nb >= 1 && nb <= BPB_HEAD_MAXB && N >= 1 && w_row_stride % 4 == 0, "bpb_pixel_dots_multi: nb=%d", nb);
+    BpbHeadMulti A = {};
+    int gx = 0, lds = 0;
+    for (int b = 0; b < nb; ++b) {
+        BPB_REQUIRE(C[b] % 4 == 0 && HW[b] >= 1 && ((uintptr_t)w[b] & 15) == 0, "bpb_pixel_dots: bad sizes (tensor %d)", b);
+        BPB_REQUIRE((long)J * C[b] * 4 <= 150 * 1024, "bpb_pixel_dots: weight rows do not fit in LDS");
+        int ppb = 64;
+        while (ppb > 16 && (long)N * bpb_cdiv(HW[b], ppb) < 1024) ppb >>= 1;
+        A.x[b] = x[b], A.a[b] = w[b], A.out[b] = out[b], A.HW[b] = HW[b], A.C[b] = C[b], A.p0[b] = ppb;
+        gx = gx > bpb_cdiv(HW[b], ppb) ? gx : bpb_cdiv(HW[b], ppb);
+        lds = lds > J * C[b] * 4 ? lds : J * C[b] * 4;
+    }
+    const dim3 grid(gx, N, nb);
+#define BPB_PD(JJ) hipLaunchKernelGGL(bpb_pixel_dots_kernel<JJ>, grid, dim3(256), lds, stream, A, w_image_stride, w_row_stride, bias)
+    BPB_DISPATCH_J(J, BPB_PD)
+#undef BPB_PD
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
 int bpb_pixel_dots(const float* x, const float* w, long w_image_stride, long w_row_stride, const float* bias, float* out, int N,
                    int HW, int C, int J, hipStream_t stream)
 {
-    BPB_REQUIRE(C % 4 == 0 && N >= 1 && HW >= 1 && w_row_stride % 4 == 0 && ((uintptr_t)w & 15) == 0, "bpb_pixel_dots: bad sizes");
-    BPB_REQUIRE((long)J * C * 4 <= 150 * 1024, "bpb_pixel_dots: weight rows do not fit in LDS");
-    int ppb = 64;
-    while (ppb > 16 && (long)N * bpb_cdiv(HW, ppb) < 1024) ppb >>= 1;
-    const dim3 grid(bpb_cdiv(HW, ppb), N);
-    const int lds = J * C * 4;
-#define BPB_PD(JJ) \
-    hipLaunchKernelGGL(bpb_pixel_dots_kernel<JJ>, grid, dim3(256), lds, stream, x, w, w_image_stride, w_row_stride, bias, out, HW, C, ppb)
-    BPB_DISPATCH_J(J, BPB_PD)
-#undef BPB_PD
+    return bpb_pixel_dots_multi(&x, &w, &out, &HW, &C, 1, w_image_stride, w_row_stride, bias, N, J, stream);
+}
+
+static int masked_pool_chunks(int N, int HW)
+{
+    int ppb = 128;
+    while (ppb > 16 && (long)N * bpb_cdiv(HW, ppb) < 512) ppb >>= 1;
+    return bpb_cdiv(HW, ppb);
+}
+
+// part_b[n][chunk][j][c] = sum_{p in chunk} m_b[n][j][p] x_b[n][p][c] for nb <= 8 tensors; part_b holds N * nchunks_b * J * C_b floats
+// (nchunks_b: bpb_masked_pool with part == nullptr)
+int bpb_masked_pool_multi(const float* const* x, const float* const* m, float* const* part, const int* HW, const int* C, int nb, int N,
+                          int J, hipStream_t stream)
+{
+    BPB_REQUIRE(nb >= 1 && nb <= BPB_HEAD_MAXB && N >= 1, "bpb_masked_pool_multi: nb=%d", nb);
+    BpbHeadMulti A = {};
+    int gx = 0, lds = 0;
+    for (int b = 0; b < nb; ++b) {
+        BPB_REQUIRE(C[b] % 4 == 0 && HW[b] >= 1, "bpb_masked_pool: bad sizes (tensor %d)", b);
+        const int nchunks = masked_pool_chunks(N, HW[b]);
+        const int c4 = C[b] >> 2, tx = c4 >= 256 ? 256 : c4, rows = 256 / tx;
+        const int slots = head_slots(HW[b], C[b], nchunks);
+        const int l = (((J + 3) & ~3) * slots + (rows - 1) * tx * J * 4) * 4;
+        BPB_REQUIRE(l <= 64 * 1024, "bpb_masked_pool: %d B of LDS", l);
+        A.x[b] = x[b], A.a[b] = m[b], A.out[b] = part[b], A.HW[b] = HW[b], A.C[b] = C[b], A.p0[b] = slots, A.p1[b] = nchunks;
+        gx = gx > nchunks ? gx : nchunks;
+        lds = lds > l ? lds : l;
+    }
+    const dim3 grid(gx, N, nb);
+#define BPB_MP(JJ) hipLaunchKernelGGL(bpb_masked_pool_kernel<JJ>, grid, dim3(256), lds, stream, A)
+    BPB_DISPATCH_J(J, BPB_MP)
+#undef BPB_MP
     BPB_LAUNCH_OK();
     return 0;
 }
@@ -744,21 +816,9 @@ int bpb_masked_pool(const float* x, const float* m, float* part, int N, int HW, 
                     hipStream_t stream)
 {
     BPB_REQUIRE(C % 4 == 0 && N >= 1 && HW >= 1, "bpb_masked_pool: bad sizes");
-    int ppb = 128;
-    while (ppb > 16 && (long)N * bpb_cdiv(HW, ppb) < 512) ppb >>= 1;
-    const int nchunks = bpb_cdiv(HW, ppb);
-    if (nchunks_out) *nchunks_out = nchunks;
+    if (nchunks_out) *nchunks_out = masked_pool_chunks(N, HW);
     if (!part) return 0;
-    const dim3 grid(nchunks, N);
-    const int c4 = C >> 2, tx = c4 >= 256 ? 256 : c4, rows = 256 / tx;
-    const int slots = head_slots(HW, C, nchunks);
-    const int lds = (((J + 3) & ~3) * slots + (rows - 1) * tx * J * 4) * 4;
-    BPB_REQUIRE(lds <= 64 * 1024, "bpb_masked_pool: %d B of LDS", lds);
-#define BPB_MP(JJ) hipLaunchKernelGGL(bpb_masked_pool_kernel<JJ>, grid, dim3(256), lds, stream, x, m, part, HW, C, slots)
-    BPB_DISPATCH_J(J, BPB_MP)
-#undef BPB_MP
-    BPB_LAUNCH_OK();
-    return 0;
+    return bpb_masked_pool_multi(&x, &m, &part, &HW, &C, 1, N, J, stream);
 }
 
 int bpb_fold_bn(const float* w, const float* b, const float* scale, const float* shift, float* wf, float* bf, int K1, int C,
@@ -810,14 +870,25 @@ int bpb_visibility(const float* probs, const unsigned char* argcls, float* vis, 
     return 0;
 }
 
+// pooled[n][j][c0_b + c] = norm_j * sum_chunks part_b[n][chunk][j][c] for nb <= 8 channel blocks of the Ct pooled channels
+int bpb_pool_finalize_multi(const float* const* part, const int* nchunks, const int* C, const int* c0, int nb, const float* pm,
+                            float* pooled, float* zinv, int N, int J, int HW, int parts_gap, int Ct, hipStream_t stream)
+{
+    BPB_REQUIRE(nb >= 1 && nb <= BPB_HEAD_MAXB, "bpb_pool_finalize_multi: nb=%d", nb);
+    BpbHeadMulti A = {};
+    for (int b = 0; b < nb; ++b) {
+        BPB_REQUIRE(c0[b] >= 0 && c0[b] + C[b] <= Ct && nchunks[b] >= 1, "bpb_pool_finalize: channel block [%d, %d) of %d", c0[b], c0[b] + C[b], Ct);
+        A.x[b] = part[b], A.p1[b] = nchunks[b], A.C[b] = C[b], A.c0[b] = c0[b];
+    }
+    hipLaunchKernelGGL(bpb_pool_finalize_kernel, dim3(J, N, nb), dim3(256), 0, stream, A, pm, pooled, zinv, J, HW, parts_gap, Ct);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
 int bpb_pool_finalize(const float* part, const float* pm, float* pooled, float* zinv, int N, int nchunks, int J, int HW,
                       int C, int parts_gap, int c0, int Ct, hipStream_t stream)
 {
-    BPB_REQUIRE(c0 >= 0 && c0 + C <= Ct, "bpb_pool_finalize: channel block [%d, %d) of %d", c0, c0 + C, Ct);
-    hipLaunchKernelGGL(bpb_pool_finalize_kernel, dim3(J, N), dim3(256), 0, stream, part, pm, pooled, zinv, nchunks, J, HW, C,
-                       parts_gap, c0, Ct);
-    BPB_LAUNCH_OK();
-    return 0;
+    return bpb_pool_finalize_multi(&part, &nchunks, &C, &c0, 1, pm, pooled, zinv, N, J, HW, parts_gap, Ct, stream);
 }
 
 int bpb_rowdot(const float* a, const float* b, float* out, int rows, int C, hipStream_t stream)

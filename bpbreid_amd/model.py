@@ -539,6 +539,13 @@ class _ModelPlan:
             nv.call('bpb_masked_pool', None, None, None, n, a.H * a.W, a.C, J, C.byref(nch), None)
             lr.nchunks.append(nch.value)
             lr.part.append(f(n * nch.value * jm * a.C))
+        # host arrays of the launches that take all branches at once (csrc/attn_pool.hip: bpb_*_multi)
+        vp = lambda vals: (C.c_void_p * nb)(*vals)
+        ia = lambda vals: (C.c_int * nb)(*vals)
+        lr.a_x, lr.a_hw, lr.a_c = vp(a.buf.data_ptr() for a in srcs), ia(a.H * a.W for a in srcs), ia(a.C for a in srcs)
+        lr.a_lb, lr.a_pmb, lr.a_dld, lr.a_part = (vp(t.data_ptr() for t in ts) for ts in (lr.lb, lr.pmb, lr.dld, lr.part))
+        lr.a_nch, lr.a_c0 = ia(lr.nchunks), ia(lr.host[b].c0 for b in range(nb))
+        lr.vp = vp
         rows = C.c_int(0)
         nv.call('bpb_lowres_stats_rows', lr.host, nb, n, C.byref(rows))
         lr.stat_rows = rows.value
@@ -661,9 +668,8 @@ class _ModelPlan:
             nv.call('bpb_fold_bn', pc.classifier.weight.data_ptr(), pc.classifier.bias.data_ptr(), self.pix_scale.data_ptr(),
                     self.pix_shift.data_ptr(), self.pix_wf.data_ptr(), self.pix_bf.data_ptr(), K1, Cc, s())
             if low:                  # W M = sum_b U_b (W_b x_b): K+1 logit channels per branch, then one up-sampling sum
-                for b, a in enumerate(lr.srcs):
-                    nv.call('bpb_pixel_dots', a.buf.data_ptr(), self.pix_wf.data_ptr() + 4 * lr.host[b].c0, 0, Cc, None,
-                            lr.lb[b].data_ptr(), n, a.H * a.W, a.C, K1, s())
+                nv.call('bpb_pixel_dots_multi', lr.a_x, lr.vp(self.pix_wf.data_ptr() + 4 * c0_ for c0_ in lr.a_c0), lr.a_lb, lr.a_hw, lr.a_c,
+                        lr.nb, 0, Cc, None, n, K1, s())
                 nv.call('bpb_lowres_upsample_sum', lr.dev.data_ptr(), lr.host, lr.nb, lr.d_lb.data_ptr(), self.pix_bf.data_ptr(),
                         self.logits_pm.data_ptr(), n, self.Hf, self.Wf, K1, s())
             else:
@@ -686,10 +692,9 @@ class _ModelPlan:
         if low:                      # sum_p a[p] M[p] = sum_q (U_b^T a)[q] x_b[q]: the masks go DOWN to the branch resolutions
             nv.call('bpb_lowres_adjoint', lr.dev.data_ptr(), lr.host, lr.nb, self.pm.data_ptr(), None, lr.d_pmb.data_ptr(), n, J,
                     self.Hf, self.Wf, s())
-            for b, a in enumerate(lr.srcs):
-                nv.call('bpb_masked_pool', a.buf.data_ptr(), lr.pmb[b].data_ptr(), lr.part[b].data_ptr(), n, a.H * a.W, a.C, J, None, s())
-                nv.call('bpb_pool_finalize', lr.part[b].data_ptr(), self.pm.data_ptr(), self.pooled.data_ptr(), self.zinv.data_ptr(),
-                        n, lr.nchunks[b], J, HW, a.C, 1 if m.parts_gap else 0, lr.host[b].c0, Cc, s())
+            nv.call('bpb_masked_pool_multi', lr.a_x, lr.a_pmb, lr.a_part, lr.a_hw, lr.a_c, lr.nb, n, J, s())
+            nv.call('bpb_pool_finalize_multi', lr.a_part, lr.a_nch, lr.a_c, lr.a_c0, lr.nb, self.pm.data_ptr(), self.pooled.data_ptr(),
+                    self.zinv.data_ptr(), n, J, HW, 1 if m.parts_gap else 0, Cc, s())
         else:
             nv.call('bpb_masked_pool', x.data_ptr(), self.pm.data_ptr(), self.pool_part.data_ptr(), n, HW, Cc, J, None, s())
             nv.call('bpb_pool_finalize', self.pool_part.data_ptr(), self.pm.data_ptr(), self.pooled.data_ptr(),
@@ -884,9 +889,8 @@ class _ModelPlan:
         if self.learnable:
             nv.call('bpb_rowdot', gpool.data_ptr(), self.pooled.data_ptr(), self.gp.data_ptr(), n * J, Cc, s())
             if low:
-                for b, a in enumerate(lr.srcs):
-                    nv.call('bpb_pixel_dots', a.buf.data_ptr(), gp_ptr + 4 * (Cc + lr.host[b].c0), J * Cc, Cc, None, lr.lb[b].data_ptr(),
-                            n, a.H * a.W, a.C, K1 + 1, s())
+                nv.call('bpb_pixel_dots_multi', lr.a_x, lr.vp(gp_ptr + 4 * (Cc + c0_) for c0_ in lr.a_c0), lr.a_lb, lr.a_hw, lr.a_c, lr.nb,
+                        J * Cc, Cc, None, n, K1 + 1, s())
                 nv.call('bpb_lowres_upsample_sum', lr.dev.data_ptr(), lr.host, lr.nb, lr.d_lb.data_ptr(), None, self.Dd.data_ptr(), n,
                         self.Hf, self.Wf, K1 + 1, s())
             else:
@@ -902,9 +906,9 @@ class _ModelPlan:
             if low:
                 nv.call('bpb_lowres_adjoint', lr.dev.data_ptr(), lr.host, lr.nb, self.dlogit.data_ptr(), None, lr.d_dld.data_ptr(), n, K1,
                         self.Hf, self.Wf, s())
+                nv.call('bpb_masked_pool_multi', lr.a_x, lr.a_dld, lr.a_part, lr.a_hw, lr.a_c, lr.nb, n, K1, s())
                 for b, a in enumerate(lr.srcs):
                     o4 = 4 * lr.host[b].c0
-                    nv.call('bpb_masked_pool', a.buf.data_ptr(), lr.dld[b].data_ptr(), lr.part[b].data_ptr(), n, a.H * a.W, a.C, K1, None, s())
                     nv.call('bpb_head_bwd_params', lr.part[b].data_ptr(), n * lr.nchunks[b], self.lpart.data_ptr(), self.nlpart, n, HW, K1,
                             a.C, Cc, pc.classifier.weight.data_ptr() + o4, pc.bn.weight.data_ptr() + o4, pc.bn.bias.data_ptr() + o4,
                             self.pix_mean.data_ptr() + o4, self.pix_invstd.data_ptr() + o4, pc.classifier.weight.grad.data_ptr() + o4,

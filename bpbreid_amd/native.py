@@ -231,7 +231,7 @@ PROTOS = {
     'bpb_maxpool3x3s2_fwd': 'pppiiiip', 'bpb_maxpool3x3s2_bwd': 'pppiiiiip',
     'bpb_bilinear_concat_fwd': 'pp', 'bpb_bilinear_concat_bwd': 'ppp', 'bpb_bilinear_concat_multi_fwd': 'ppipipp',
     'bpb_bilinear_concat_multi_bwd': 'ppip',
-    'bpb_pixel_dots': 'ppllppiiiip', 'bpb_masked_pool': 'pppiiiipp', 'bpb_fold_bn': 'ppppppiip',
+    'bpb_pixel_dots': 'ppllppiiiip', 'bpb_pixel_dots_multi': 'pppppillpiip', 'bpb_masked_pool_multi': 'pppppiiip', 'bpb_pool_finalize_multi': 'ppppipppiiiiip', 'bpb_masked_pool': 'pppiiiipp', 'bpb_fold_bn': 'ppppppiip',
     'bpb_softmax_masks': 'ppppppiiip', 'bpb_visibility': 'ppppiiiipp', 'bpb_pool_finalize': 'ppppiiiiiiiip',
     'bpb_rowdot': 'pppiip', 'bpb_resize_masks': 'ppiiiiiip', 'bpb_attention_from_masks': 'pppppiiiiip', 'bpb_head_bwd_dlogits': 'pppppppppiiipppp',
     'bpb_head_bwd_params': 'pipiiiiiipppppppppppip', 'bpb_head_bwd_dx': 'ppppppppppppiiiiip',
@@ -258,7 +258,7 @@ EXPORTS = [
     'bpb_head_bwd_params', 'bpb_head_bwd_dx', 'bpb_gemm', 'bpb_gemm_grouped', 'bpb_colsum', 'bpb_bn1d_fwd', 'bpb_bn1d_bwd',
     'bpb_ce_label_smooth', 'bpb_ce_weight_grad', 'bpb_pixel_ce', 'bpb_part_triplet', 'bpb_part_triplet_bwd', 'bpb_scale', 'bpb_adam_step',
     'bpb_fill', 'bpb_plan_run', 'bpb_plan_run_timed', 'bpb_part_distance', 'bpb_part_distance_fill', 'bpb_l2_normalize_rows', 'bpb_eval_rank',
-    'bpb_mask_preprocess', 'bpb_re_ranking', 'bpb_re_ranking_gpu', 'bpb_re_ranking_gpu_workspace', 'bpb_eval_rank_gpu', 'bpb_bn_eval_affine_batched', 'bpb_resize_masks', 'bpb_attention_from_masks', 'bpb_conv_s1_init', 'bpb_conv_s1', 'bpb_wgrad16_init', 'bpb_conv_wgrad16', 'bpb_wgrad1x1_init', 'bpb_conv_wgrad1x1', 'bpb_fuse_fwd_multi', 'bpb_term_bwd_multi', 'bpb_bn_finalize_multi',
+    'bpb_mask_preprocess', 'bpb_re_ranking', 'bpb_re_ranking_gpu', 'bpb_re_ranking_gpu_workspace', 'bpb_eval_rank_gpu', 'bpb_bn_eval_affine_batched', 'bpb_resize_masks', 'bpb_attention_from_masks', 'bpb_pixel_dots_multi', 'bpb_masked_pool_multi', 'bpb_pool_finalize_multi', 'bpb_conv_s1_init', 'bpb_conv_s1', 'bpb_wgrad16_init', 'bpb_conv_wgrad16', 'bpb_wgrad1x1_init', 'bpb_conv_wgrad1x1', 'bpb_fuse_fwd_multi', 'bpb_term_bwd_multi', 'bpb_bn_finalize_multi',
     'bpb_bn_bwd_finalize_multi', 'bpb_wgrad_reduce_multi',
     'bpb_weighted_sum', 'bpb_scalar_fanout', 'bpb_lowres_stats_rows', 'bpb_lowres_stats', 'bpb_lowres_upsample_sum', 'bpb_lowres_adjoint', 'bpb_lowres_dx',
 ]

@@ -417,8 +417,13 @@ int bpb_bilinear_concat_multi_bwd(const BpbBilinearBwdDesc* d_descs, const BpbBi
  * matrix; a column block of a wider matrix otherwise: the per-branch slices of the low-resolution head) */
 int bpb_pixel_dots(const float* x, const float* w, long w_image_stride, long w_row_stride, const float* bias, float* out, int N,
                    int HW, int C, int J, hipStream_t stream);
+/* the same pass over nb <= 8 tensors x_b [N][HW_b][C_b] in ONE launch (the head on the HRNet branch outputs: host arrays of nb pointers / sizes) */
+int bpb_pixel_dots_multi(const float* const* x, const float* const* w, float* const* out, const int* HW, const int* C, int nb,
+                         long w_image_stride, long w_row_stride, const float* bias, int N, int J, hipStream_t stream);
 int bpb_masked_pool(const float* x, const float* m, float* part, int N, int HW, int C, int J, int* nchunks_out,
                     hipStream_t stream);
+int bpb_masked_pool_multi(const float* const* x, const float* const* m, float* const* part, const int* HW, const int* C, int nb, int N,
+                          int J, hipStream_t stream);
 int bpb_fold_bn(const float* w, const float* b, const float* scale, const float* shift, float* wf, float* bf, int K1, int C,
                 hipStream_t stream);
 int bpb_softmax_masks(const float* logits, float* scores, float* probs, float* pm, unsigned char* argpart,
@@ -437,6 +442,8 @@ int bpb_visibility(const float* probs, const unsigned char* argcls, float* vis, 
  * (GlobalAveragePoolingHead, bpbreid.py:432-441, :485-486) instead of 'gwap' (bpbreid.py:490-503) */
 int bpb_pool_finalize(const float* part, const float* pm, float* pooled, float* zinv, int N, int nchunks, int J, int HW,
                       int C, int parts_gap, int c0, int Ct, hipStream_t stream);
+int bpb_pool_finalize_multi(const float* const* part, const int* nchunks, const int* C, const int* c0, int nb, const float* pm,
+                            float* pooled, float* zinv, int N, int J, int HW, int parts_gap, int Ct, hipStream_t stream);
 /* (`part` holds the channels [c0, c0 + C) of the Ct pooled channels: c0 = 0, Ct = C for a materialised map) */
 int bpb_rowdot(const float* a, const float* b, float* out, int rows, int C, hipStream_t stream);
 int bpb_head_bwd_dlogits(const float* D, const float* probs, const unsigned char* argpart, const float* zinv,
