@@ -39,7 +39,8 @@ __device__ unsigned long long* g_s1_trace = nullptr;
 #endif
 // Ablation switches of the measurement build (results are WRONG with any of them; they answer "what does a chunk's time consist
 // of"): 1 no DMA after the first chunk, 2 no barrier after the first chunk, 4 no LDS reads inside the MFMA loop, 8 no per-chunk
-// accumulator bookkeeping, 16 no address updates.
+// accumulator bookkeeping, 16 no address updates, 32 DMA offsets without the index arithmetic (lane * 16: what would a free prologue
+// buy?), 64 no epilogue (no stores, no statistics: what would a free epilogue buy?).
 #ifndef S1_ABL
 #define S1_ABL 0
 #endif
@@ -136,7 +137,8 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob
 #pragma unroll
     for (int k = 0; k < DMA_HS; ++k) {
         unsigned vo = DMA_OOB;
-        if (k < nhs) {
+        if ((S1_ABL & 32) && k < nhs) vo = (unsigned)((k * 256 + (int)threadIdx.x) * 16);
+        else if (k < nhs) {
             const int idx = k * 256 + (int)threadIdx.x;
             const unsigned hp = s1_fdiv((unsigned)idx, spp, P.magic_spp);
             const int v = idx - (int)M24(hp, spp);
@@ -155,7 +157,8 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob
 #pragma unroll
     for (int k = 0; k < DMA_WS; ++k) {
         unsigned vo = DMA_OOB;
-        if (k < nws) {
+        if ((S1_ABL & 32) && k < nws) vo = (unsigned)((k * 256 + (int)threadIdx.x) * 16);
+        else if (k < nws) {
             const int bi = k * 256 + (int)threadIdx.x;
             const int n = bi & (NTC - 1);
             const int r = bi >> lNTC;
@@ -331,6 +334,11 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob
                     for (int e = 0; e < 4; ++e) acc[mt][nt][q * 4 + e] += v[q][e];
             }
     }
+    if (S1_ABL & 64) {
+        if (acc[0][0][0] == 12345.678f) P.y[threadIdx.x] = acc[0][0][1];      // (keeps the accumulators alive)
+        S1_TR(4);
+        return;
+    }
     // ---- epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31 (channel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
     // Stores (and the loads of the accumulate mode) go through a buffer descriptor; an invalid pixel adds 2^31 and an invalid
     // channel 2^30 to the 32-bit offset, so every invalid combination is dropped by the hardware (y is <= 1 GiB, host check).
@@ -388,8 +396,68 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob
         ssum[nt] = 0.0;
         ssq[nt] = 0.0;
     }
+    // ---- forward epilogue through an LDS transpose (P.tstore; single-tile waves).  In the MFMA layout a lane owns ONE channel of
+    // 16 pixels: 16 four-byte stores (and 16 loads of the residual) per lane, two 128-byte segments per instruction -- for the
+    // 32-channel branch these are 40 % of the wave's memory instructions (16 of 16 + 4 x 6), and the memory pipe of the CU, not the
+    // MFMA pipe, is what the short workgroups wait for (tools/s1_trace.py ablation 64: a launch without epilogues is 8-9 %
+    // shorter).  Here the wave writes its 32 x 32 tile into the staging buffer the last chunk did not use and reads it back as
+    // [pixel][4 channels]: 4 sixteen-byte stores (+ 4 loads) per lane, 4 offsets instead of 16.
+    bool tdone = false;
+    if constexpr (MT == 1 && NT == 1) {
+        if (P.tstore) {
+            tdone = true;
+            const bool has_res = P.res != nullptr;
+            float* tile = (float*)((char*)smem + redbase) + wave * 1024;       // [32 pixels][32 channels] of this wave
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[0][0][r] + bias_v[0];
+                if (relu && !has_res) v = fmaxf(v, 0.f);
+                if (do_stats) {
+                    // pixels of a ragged tile beyond the image do not count (their taps read real neighbours); padding channels are
+                    // never stored below.  fp64 from the first element on, as in the per-register path
+                    const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
+                    const double dv = (n0 + ti < P.N && a0 + th < P.H && b0 + tw < P.W) ? (double)v : 0.0;
+                    ssum[0] += dv;
+                    ssq[0] += dv * dv;
+                }
+                tile[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = v;
+            }
+            const int trow = lane >> 3, cq = lane & 7;
+            const int cout_t = ntile * NTC + wni * 32 + cq * 4;
+            const bool cvq = cout_t < Cout;                                   // (Cout % 4 == 0: a quad is valid or not as a whole)
+            using b128_t = decltype(__builtin_amdgcn_raw_buffer_load_b128(ry, 0, 0, 0));
+            f32x4 tv[4];
+            unsigned toff[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                tv[i] = *(const f32x4*)(tile + (trow + 8 * i) * 32 + cq * 4);
+                const int m = wm * 32 + trow + 8 * i;
+                const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
+                const int n = n0 + ti, a = a0 + th, b = b0 + tw;
+                const bool pv = (n < P.N) && (a < P.H) && (b < P.W) && cvq;
+                toff[i] = pv ? M24(M24(M24(n, P.H) + a, P.W) + b, pstride) + (unsigned)(cout_t * 4) : PIX_OOB;
+            }
+            if (has_res) {
+                f32x4 ov[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ov[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rold, (int)toff[i], 0, 0));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = tv[i][e] + ov[i][e];
+                        tv[i][e] = relu ? fmaxf(v, 0.f) : v;
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(b128_t, tv[i]), ry, (int)toff[i], 0, 0);
+            if (do_stats) __syncthreads();        // the partial sums below reuse the tiles' memory
+        }
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+        if (tdone) break;
         unsigned offs[16];
         if (lTW >= 2) {
             // tile width >= 4: the four rows (r & 3) of a register quad are four consecutive pixels of one image row
@@ -577,6 +645,9 @@ int bpb_conv_s1(const BpbConvS1Prob* d_probs, const BpbConvS1Prob* h_probs, int 
                         p.n_ntiles == bpb_cdiv(p.Cout, (32 * nt) << p.lwn),
                     "bpb_conv_s1: tile counts mismatch");
         BPB_REQUIRE(p.blk_begin == nblk, "bpb_conv_s1: blk_begin mismatch");
+        BPB_REQUIRE(p.tstore == 0 || (nt == 1 && mt == 1 && p.accumulate == 0 && p.bnb == nullptr && (p.stats == nullptr || p.res == nullptr) &&
+                                      conv_s1_lds_bytes(p) >= 2 * 16384),
+                    "bpb_conv_s1: the transposed epilogue is for plain forward problems of single-tile waves with >= 16 KiB staging buffers");
         BPB_REQUIRE(p.split == nullptr || ((p.Cin / p.CK) % 2 == 0 && (double)p.n_mtiles * p.n_ntiles * mt * nt * 16384.0 < 2147483648.0),
                     "bpb_conv_s1: a K split needs an even number of channel chunks (Cin=%d, CK=%d) and < 2 GiB of hand-over space", p.Cin, p.CK);
         const int npix = (1 << p.lTI) * p.HH * p.HW;

@@ -137,6 +137,7 @@ typedef struct BpbConvS1Prob {
     int S;                  // stride 1 or 2 (2: forward only; H, W are the OUTPUT extent, HH = (TH - 1) * S + R)
     int Hi, Wi;             // input extent (= H, W for stride 1)
     int xr;                 // 1: XCD-aware block -> tile map (block b runs on XCD b % 8: every XCD walks a contiguous range of tiles)
+    int tstore;             // 1: epilogue through an LDS transpose, 16-byte stores (plain forward problems of single-tile waves)
 } BpbConvS1Prob;
 
 /* weight-gradient problem: dW[t][ci][co] = sum_{n,a,b} x[n, a*sa + t/S + ih0, b*sa + t%S + iw0, ci] * dy[n,a,b,co] */
