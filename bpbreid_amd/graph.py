@@ -404,8 +404,12 @@ class Net:
         p.x_bytes, p.w_bytes, p.y_bytes = x_buf.numel() * 4, w_packed.numel() * 4, y_buf.numel() * 4
         p.magic_spp, p.magic_hw, p.magic_hh = magic(p.LD // 4), magic(hw), magic(hh)
         p.magic_nt, p.magic_tb, p.magic_ta = magic(p.n_ntiles), magic(p.tiles_b), magic(p.tiles_a)
-        # forward problems of single-tile waves store through an LDS transpose (16-byte stores, csrc/conv_s1.hip)
-        p.tstore = 1 if (os.environ.get('BPB_S1_TSTORE', '1') != '0' and (mt_r, nt) == (1, 1) and not accumulate and not wflip
+        # forward problems of single-tile waves WITHOUT BatchNorm statistics (the eval plan: conv + folded BatchNorm + residual + ReLU)
+        # store through an LDS transpose (16-byte stores, csrc/conv_s1.hip).  With the statistics the per-channel sums want the MFMA
+        # layout (a lane owns a channel): the transposed form then pays pixel-validity arithmetic and a barrier on top and measured
+        # 13 % SLOWER on the three-branch launches of the training plan (BPB_S1_TSTORE=2 forces it there, profiles/r03_*).
+        ts = os.environ.get('BPB_S1_TSTORE', '1')
+        p.tstore = 1 if (ts != '0' and (mt_r, nt) == (1, 1) and not accumulate and not wflip and (stats is None or ts == '2')
                          and lds_of(p.LD) >= 2 * 16384) else 0
         if stats is not None:
             st_buf = torch.empty(p.n_mtiles * 2 * cout, device=self.device, dtype=torch.float64)
