@@ -16,8 +16,9 @@
 #define BPB_HEAD_MAXJ 12
 
 // The head on the branch outputs of HRNet (csrc/head_lowres.hip) runs the same small pass over four tensors of different
-// resolution and width: one launch takes up to 8 of them (blockIdx.z = branch, parameters by value, blocks beyond a branch's own
-// grid return at once) instead of four launches of 8-23 us that mostly wait for each other's tail.
+// resolution and width: one launch takes up to 8 of them (parameters by value; blockIdx.x runs over the blocks of all branches one
+// after another -- a (max blocks, N, branch) grid with early exits measured SLOWER than four launches: 4352 of its 8192 workgroups
+// were empty) instead of four launches of 8-23 us that mostly wait for each other's tail.
 #define BPB_HEAD_MAXB 8
 struct BpbHeadMulti {
     const float* x[BPB_HEAD_MAXB];      // the branch tensors [N][HW_b][C_b]  (pool_finalize: the pooling partials)
@@ -26,6 +27,7 @@ struct BpbHeadMulti {
     int HW[BPB_HEAD_MAXB], C[BPB_HEAD_MAXB];
     int p0[BPB_HEAD_MAXB];              // pixels per block (pixel_dots) / LDS pixel slots (masked_pool)
     int p1[BPB_HEAD_MAXB];              // blocks along x of this branch (masked_pool, pool_finalize: nchunks)
+    int bx0[BPB_HEAD_MAXB];             // first blockIdx.x of the branch (pixel_dots, masked_pool); unused entries INT_MAX
     int c0[BPB_HEAD_MAXB];              // first channel of the branch inside the concatenated width (pool_finalize)
 };
 
@@ -34,12 +36,15 @@ template <int J>
 __global__ __launch_bounds__(256) void bpb_pixel_dots_kernel(BpbHeadMulti A, long w_image_stride, long w_row_stride, const float* __restrict__ bias)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // w rows [J][C]
-    const int br = blockIdx.z;
+    int br = 0;
+#pragma unroll
+    for (int i = 1; i < BPB_HEAD_MAXB; ++i)
+        if ((int)blockIdx.x >= A.bx0[i]) br = i;
+    const int bx = (int)blockIdx.x - A.bx0[br];
     const float* __restrict__ x = A.x[br];
     const float* __restrict__ w = A.a[br];
     float* __restrict__ out = A.out[br];
     const int HW = A.HW[br], C = A.C[br], pix_per_block = A.p0[br];
-    if ((int)blockIdx.x * pix_per_block >= HW) return;
     const int n = blockIdx.y;
     const float* wn = w + (long)n * w_image_stride;
     for (int i = threadIdx.x; i < J * (C >> 2); i += 256) {
@@ -49,19 +54,24 @@ __global__ __launch_bounds__(256) void bpb_pixel_dots_kernel(BpbHeadMulti A, lon
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c4 = C >> 2;
-    const int p_begin = blockIdx.x * pix_per_block, p_end = min(HW, p_begin + pix_per_block);
+    const int p_begin = bx * pix_per_block, p_end = min(HW, p_begin + pix_per_block);
+    // G lanes share a pixel (the smallest power of two >= min(C/4, 64) channel quads), 64 / G pixels ride in one wave pass: a
+    // 32-channel branch output keeps all lanes busy (one pixel per pass left 56 of 64 lanes idle and six shuffle steps per sum)
+    int G = 64;
+    while (G > 1 && (G >> 1) >= c4) G >>= 1;
+    const int PW = 64 / G, sub = lane / G, cql = lane - sub * G;
     constexpr int PB = 4;
-    for (int p0 = p_begin + wave * PB; p0 < p_end; p0 += 4 * PB) {
+    for (int p0 = p_begin + wave * PB * PW; p0 < p_end; p0 += 4 * PB * PW) {
         float acc[PB][J];
 #pragma unroll
         for (int b = 0; b < PB; ++b)
 #pragma unroll
             for (int j = 0; j < J; ++j) acc[b][j] = 0.f;
-        for (int cq = lane; cq < c4; cq += 64) {
+        for (int cq = cql; cq < c4; cq += G) {
             f32x4 xv[PB];
 #pragma unroll
             for (int b = 0; b < PB; ++b) {
-                const int p = min(p0 + b, p_end - 1);
+                const int p = min(p0 + b * PW + sub, p_end - 1);
                 xv[b] = *(const f32x4*)(x + ((long)n * HW + p) * C + cq * 4);
             }
 #pragma unroll
@@ -77,19 +87,20 @@ __global__ __launch_bounds__(256) void bpb_pixel_dots_kernel(BpbHeadMulti A, lon
 #pragma unroll
             for (int j = 0; j < J; ++j) {
                 float v = acc[b][j];
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+                for (int o = G >> 1; o >= 1; o >>= 1) v += __shfl_xor(v, o);       // (stays inside the aligned group of G lanes)
                 acc[b][j] = v;
             }
-        if (lane < PB * J) {
-            const int b = lane / J, j = lane - b * J;
+        // every lane of a group holds the sums of its PB pixels: lane t of the group stores the (b, j) pairs t, t + G, ...
+        for (int idx = cql; idx < PB * J; idx += G) {
+            const int b = idx / J, j = idx - b * J;
             float v = 0.f;
 #pragma unroll
             for (int bb = 0; bb < PB; ++bb)
 #pragma unroll
                 for (int jj = 0; jj < J; ++jj)
                     if (bb == b && jj == j) v = acc[bb][jj];
-            if (p0 + b < p_end) out[((long)n * HW + p0 + b) * J + j] = v + (bias ? bias[j] : 0.f);
+            const int p = p0 + b * PW + sub;
+            if (p < p_end) out[((long)n * HW + p) * J + j] = v + (bias ? bias[j] : 0.f);
         }
     }
 }
@@ -122,13 +133,15 @@ __global__ __launch_bounds__(256) void bpb_masked_pool_kernel(BpbHeadMulti A)
 {
     constexpr int JP = (J + 3) & ~3;                              // mask rows padded to whole float4s
     extern __shared__ __attribute__((aligned(16))) float smem[];   // masks [slots][JP], then the row partials
-    const int br = blockIdx.z;
+    int br = 0;
+#pragma unroll
+    for (int i = 1; i < BPB_HEAD_MAXB; ++i)
+        if ((int)blockIdx.x >= A.bx0[i]) br = i;
     const float* __restrict__ x = A.x[br];
     const float* __restrict__ m = A.a[br];
     float* __restrict__ part = A.out[br];
     const int HW = A.HW[br], C = A.C[br], slots = A.p0[br];
-    const int n = blockIdx.y, chunk = blockIdx.x, nchunks = A.p1[br];
-    if (chunk >= nchunks) return;
+    const int n = blockIdx.y, chunk = (int)blockIdx.x - A.bx0[br], nchunks = A.p1[br];
     const int c4 = C >> 2;
     const int tx = c4 >= 256 ? 256 : c4, rows = 256 / tx;
     const int G = rows * HEAD_U;
@@ -753,17 +766,18 @@ int bpb_pixel_dots_multi(const float* const* x, const float* const* w, float* co
 {
     BPB_REQUIRE(nb >= 1 && nb <= BPB_HEAD_MAXB && N >= 1 && w_row_stride % 4 == 0, "bpb_pixel_dots_multi: nb=%d", nb);
     BpbHeadMulti A = {};
+    for (int b = 0; b < BPB_HEAD_MAXB; ++b) A.bx0[b] = 0x7fffffff;
     int gx = 0, lds = 0;
     for (int b = 0; b < nb; ++b) {
         BPB_REQUIRE(C[b] % 4 == 0 && HW[b] >= 1 && ((uintptr_t)w[b] & 15) == 0, "bpb_pixel_dots: bad sizes (tensor %d)", b);
         BPB_REQUIRE((long)J * C[b] * 4 <= 150 * 1024, "bpb_pixel_dots: weight rows do not fit in LDS");
         int ppb = 64;
         while (ppb > 16 && (long)N * bpb_cdiv(HW[b], ppb) < 1024) ppb >>= 1;
-        A.x[b] = x[b], A.a[b] = w[b], A.out[b] = out[b], A.HW[b] = HW[b], A.C[b] = C[b], A.p0[b] = ppb;
-        gx = gx > bpb_cdiv(HW[b], ppb) ? gx : bpb_cdiv(HW[b], ppb);
+        A.x[b] = x[b], A.a[b] = w[b], A.out[b] = out[b], A.HW[b] = HW[b], A.C[b] = C[b], A.p0[b] = ppb, A.bx0[b] = gx;
+        gx += bpb_cdiv(HW[b], ppb);
         lds = lds > J * C[b] * 4 ? lds : J * C[b] * 4;
     }
-    const dim3 grid(gx, N, nb);
+    const dim3 grid(gx, N);
 #define BPB_PD(JJ) hipLaunchKernelGGL(bpb_pixel_dots_kernel<JJ>, grid, dim3(256), lds, stream, A, w_image_stride, w_row_stride, bias)
     BPB_DISPATCH_J(J, BPB_PD)
 #undef BPB_PD
@@ -791,6 +805,7 @@ int bpb_masked_pool_multi(const float* const* x, const float* const* m, float* c
 {
     BPB_REQUIRE(nb >= 1 && nb <= BPB_HEAD_MAXB && N >= 1, "bpb_masked_pool_multi: nb=%d", nb);
     BpbHeadMulti A = {};
+    for (int b = 0; b < BPB_HEAD_MAXB; ++b) A.bx0[b] = 0x7fffffff;
     int gx = 0, lds = 0;
     for (int b = 0; b < nb; ++b) {
         BPB_REQUIRE(C[b] % 4 == 0 && HW[b] >= 1, "bpb_masked_pool: bad sizes (tensor %d)", b);
@@ -799,11 +814,11 @@ int bpb_masked_pool_multi(const float* const* x, const float* const* m, float* c
         const int slots = head_slots(HW[b], C[b], nchunks);
         const int l = (((J + 3) & ~3) * slots + (rows - 1) * tx * J * 4) * 4;
         BPB_REQUIRE(l <= 64 * 1024, "bpb_masked_pool: %d B of LDS", l);
-        A.x[b] = x[b], A.a[b] = m[b], A.out[b] = part[b], A.HW[b] = HW[b], A.C[b] = C[b], A.p0[b] = slots, A.p1[b] = nchunks;
-        gx = gx > nchunks ? gx : nchunks;
+        A.x[b] = x[b], A.a[b] = m[b], A.out[b] = part[b], A.HW[b] = HW[b], A.C[b] = C[b], A.p0[b] = slots, A.p1[b] = nchunks, A.bx0[b] = gx;
+        gx += nchunks;
         lds = lds > l ? lds : l;
     }
-    const dim3 grid(gx, N, nb);
+    const dim3 grid(gx, N);
 #define BPB_MP(JJ) hipLaunchKernelGGL(bpb_masked_pool_kernel<JJ>, grid, dim3(256), lds, stream, A)
     BPB_DISPATCH_J(J, BPB_MP)
 #undef BPB_MP
