@@ -95,7 +95,60 @@ CONV_CASES = [
     (2, 4, 6, 136, 144, 1, 1, 0),      # ... 256 x 64 tiles, three of them along the output channels
     (2, 4, 6, 128, 128, 1, 1, 0),      # ... 128 x 128 tile
     (3, 9, 7, 64, 128, 1, 2, 0),       # ... stride 2 (ResNet downsample): gathers input pixel (2a, 2b)
+    (8, 8, 4, 16, 32, 3, 1, 1),        # four whole 8x4 maps per tile: the halo is staged unpadded (LD = CK), see below
 ]
+
+
+def test_grouped_conv_policies_k_split_unpadded_halo_transposed_epilogue(monkeypatch):
+    """Plan-time switches of the grouped 3x3 launches: the deepest problem of a four-branch module step takes
+    two workgroups per tile (BpbS1Split) when it has >= BPB_S1_SPLIT_RATIO times the MFMAs per wave of the lightest one; the
+    8x4-map problem stages its halo unpadded so that the launch keeps four workgroups per CU; forward problems without
+    BatchNorm statistics use the transposed epilogue, data gradients and problems with statistics do not."""
+    branches = [(64, 32, 32), (32, 16, 64), (16, 8, 128), (8, 4, 256)]
+
+    def build(nb, stats):
+        net = Net(torch.device('cpu'))
+        net.fork(max(2, nb))
+        for i, (h, w, c) in enumerate(branches[:nb]):
+            net.set_slot(i)
+            x = Act(net, 64, h, w, c)
+            x.needs_grad = True
+            wt = torch.zeros(c, c, 3, 3)
+            wt.grad = torch.zeros_like(wt)
+            bn = None
+            if stats:
+                bn = tuple(torch.zeros(c) for _ in range(4))
+                bn[0].grad, bn[1].grad = torch.zeros(c), torch.zeros(c)
+            node = net.conv(x, wt, 1, 1, bn=bn)
+            if stats:
+                net.fuse([(node, 0)], relu=True)
+        net.set_slot(0)
+        net.join(max(2, nb))
+        net.finalize(train_backward=stats)
+        return net, [p for p, *_ in net.debug_convs if isinstance(p, nv.ConvS1Prob)]
+
+    net, probs = build(4, False)
+    by_c = {p.Cin: p for p in probs}
+    assert by_c[256].split and not any(by_c[c].split for c in (32, 64, 128))
+    assert by_c[256].LD == by_c[256].CK and all(by_c[c].LD == by_c[c].CK + 4 for c in (32, 64, 128))
+    assert all(p.tstore == 1 for p in probs)
+    op = [o for o, m in zip(net.plan_eval[0], net.plan_eval[2]) if m['label'].startswith('conv_fwd')][0]
+    assert op.i[0] == 4 and op.i[1] == 1024 + 512 + 256 + 2 * 128          # the split problem takes both halves' blocks
+    assert net.split_flags and net.split_flags[0][1] == 128
+    _, probs3 = build(3, False)
+    assert not any(p.split for p in probs3)                              # 128 channels: 4x the lightest, below the ratio
+    monkeypatch.setenv('BPB_S1_SPLIT_RATIO', '4')
+    _, probs3 = build(3, False)
+    assert [bool(p.split) for p in sorted(probs3, key=lambda p: p.Cin)] == [False, False, True]
+    monkeypatch.setenv('BPB_S1_SPLIT_RATIO', '0')
+    _, probs0 = build(4, False)
+    assert not any(p.split for p in probs0)
+    monkeypatch.delenv('BPB_S1_SPLIT_RATIO')
+    _, probs_t = build(4, True)                                           # training plan: statistics -> MFMA-layout epilogue
+    fwd = [p for p in probs_t if not p.wflip]
+    dgrad = [p for p in probs_t if p.wflip]
+    assert fwd and dgrad and all(p.tstore == 0 for p in fwd + dgrad)
+    assert any(p.split for p in fwd) and any(p.split for p in dgrad)
 
 
 @pytest.mark.parametrize('case', CONV_CASES)
