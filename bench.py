@@ -338,6 +338,9 @@ def main():
                    'backbone_launches_per_step': sum(p_[1] for p_ in (next(iter(model._plans.values())).net.plan_train,
                                                                        next(iter(model._plans.values())).net.plan_bwd))},
     }
+    # a K-split convolution workgroup that ever gave up waiting for its partner (bounded spin, csrc/conv_s1.hip) voids the run
+    lost = sum(pl.net.split_timeouts() for pl in model._plans.values())
+    assert lost == 0, '%d K-split hand-overs timed out' % lost
     if exchange is not None:
         result['config']['gradient_exchange'] = exchange
         # the line is only valid if the collective really spanned the ranks the driver asked for
