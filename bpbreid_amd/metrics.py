@@ -87,9 +87,11 @@ def evaluate_rank(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50, eval
         return _evaluate_cuhk03(distmat, q_pids, g_pids, q_camids, g_camids, max_rank, nthreads)
     if eval_metric != 'default':
         raise ValueError("Incorrect eval_metric value '{}'".format(eval_metric))
-    if isinstance(distmat, torch.Tensor) and distmat.is_cuda and not return_indices:
+    if isinstance(distmat, torch.Tensor) and distmat.is_cuda:
         res = _evaluate_rank_gpu(distmat, q_pids, g_pids, q_camids, g_camids, max_rank)
         if res is not None:
+            if return_indices:               # the index matrix of rank.py:110 from the GPU sort, handed out like the host one
+                res['indices'] = argsort_rows_gpu(distmat).cpu().numpy()
             return res
     if isinstance(distmat, torch.Tensor):
         distmat = distmat.cpu().numpy()
@@ -138,6 +140,20 @@ def _evaluate_rank_gpu(distmat, q_pids, g_pids, q_camids, g_camids, max_rank):
     if nvalid == 0:
         raise AssertionError('Error: all query identities do not appear in gallery')
     return {'cmc': cmc.cpu().numpy(), 'mAP': float(mAP.item())}
+
+
+def argsort_rows_gpu(distmat):
+    """Row-wise stable argsort of a CUDA fp32 matrix (csrc/argsort_gpu.hip): int32 CUDA tensor [Q, G], ties by the lower index --
+    np.argsort(distmat, axis=1, kind='stable') without leaving HBM (rank.py:110)."""
+    dm = distmat.to(torch.float32).contiguous()
+    nv.same_device(dm, 'argsort_rows_gpu')
+    nq, ng = dm.shape
+    need = C.c_long(0)
+    nv.call('bpb_argsort_rows_gpu_workspace', nq, ng, C.byref(need))
+    ws = torch.empty(need.value, device=dm.device, dtype=torch.uint8)
+    idx = torch.empty(nq, ng, device=dm.device, dtype=torch.int32)
+    nv.call('bpb_argsort_rows_gpu', dm.data_ptr(), nq, ng, idx.data_ptr(), ws.data_ptr(), need.value, nv.stream())
+    return idx
 
 
 def _native_argsort(dm, nthreads=None):

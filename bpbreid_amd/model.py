@@ -882,10 +882,10 @@ class _ModelPlan:
         # ---- attention head backward
         x = self.feats.buf
         pc = m.pixel_classifier
-        gfe = g['feats']
-        if gfe is not None:
-            raise NotImplementedError('external gradient on spatial_features')
         low, lr = self.low, self.lr
+        gfe = g['feats']                 # gradient on spatial_features (bpbreid.py:222-259 returns the map as a differentiable output)
+        if gfe is not None and low:
+            raise RuntimeError('bpbreid_amd: spatial_features is not materialised in this mode (need_spatial_features=True)')
         if self.learnable:
             nv.call('bpb_rowdot', gpool.data_ptr(), self.pooled.data_ptr(), self.gp.data_ptr(), n * J, Cc, s())
             if low:
@@ -938,6 +938,10 @@ class _ModelPlan:
                     self.dlogit.data_ptr(), pc.classifier.weight.data_ptr(), pc.bn.weight.data_ptr(), self.pix_mean.data_ptr(),
                     self.pix_invstd.data_ptr(), self.k1.data_ptr(), self.k2.data_ptr(), self.feats.grad.data_ptr(), n, HW, Cc, K1,
                     0, s())
+            if gfe is not None:          # the map is handed out as an NCHW view of the NHWC plan buffer: the gradient goes the same way
+                gn = gfe.to(torch.float32).permute(0, 2, 3, 1).contiguous()
+                nv.same_device(gn, 'BPBreID.backward')
+                nv.call('bpb_scale', gn.data_ptr(), None, 1.0, self.feats.grad.data_ptr(), gn.numel(), 1, s())
         hook = getattr(m, '_bucket_hook', None)
         if hook is None:
             net.run(net.plan_bwd, first)
@@ -970,7 +974,8 @@ class _ModelFn(torch.autograd.Function):
         ctx.plan = plan
         ctx.training = training
         ctx.generation = plan.generation
-        ctx.mark_non_differentiable(outs[-3])                  # spatial features (an empty placeholder when not materialised)
+        if plan.low or not training:
+            ctx.mark_non_differentiable(outs[-3])              # spatial features: an empty placeholder when not materialised
         if not plan.learnable:
             ctx.mark_non_differentiable(outs[-4])              # no pixel classifier output
         if plan.binary or not plan.learnable or not training:

@@ -572,6 +572,11 @@ int bpb_re_ranking(const float* q_g_dist, const float* q_q_dist, const float* g_
  * metrics/rank.py:97-159 */
 int bpb_eval_rank_gpu(const float* distmat, const long* q_pids, const long* g_pids, const long* q_camids, const long* g_camids,
                       int Q, int G, int max_rank, double* work, int* iwork, float* cmc, double* map_out, hipStream_t stream);
+/* the ranked gallery indices of every query on the GPU (csrc/argsort_gpu.hip): row-wise STABLE argsort of a [Q][G] fp32 matrix
+ * in HBM, ties by the lower gallery index like np.argsort(kind='stable') and bpb_eval_rank's index matrix.  idx_out int32 [Q][G];
+ * ws: caller-provided device workspace of the size the _workspace call reports.  metrics/rank.py:110 */
+int bpb_argsort_rows_gpu_workspace(int Q, int G, long* bytes_out);
+int bpb_argsort_rows_gpu(const float* dist, int Q, int G, int* idx_out, void* ws, long ws_bytes, hipStream_t stream);
 /* the same on the GPU (csrc/rerank_gpu.hip): device pointers in and out, dense (Q+G)^2 work matrices in caller-provided
  * workspace (sizes from bpb_re_ranking_gpu_workspace, in elements); k1 + 1 <= 32 and k2 <= 32.  utils/rerank.py:30-117 */
 int bpb_re_ranking_gpu_workspace(int Q, int G, int k1, int k2, long* fwork_floats, long* iwork_ints);

@@ -595,6 +595,37 @@ def test_part_distance_large_ranking_identical_to_oracle():
     assert np.allclose(a['cmc'], b['cmc'], atol=1e-6) and abs(a['mAP'] - b['mAP']) < 1e-6
 
 
+def test_gpu_argsort_is_the_stable_argsort_of_numpy_and_of_the_host_routine():
+    """csrc/argsort_gpu.hip (rank.py:110 on the GPU): identical to np.argsort(kind='stable') on tie-free rows, under heavy ties
+    (quantised distances, the -1 -> max + 1 fill value repeated) and ragged sizes; at the full evaluation size every row is a
+    permutation that sorts its distances and equals the host routine's index matrix; evaluate_rank hands it out."""
+    from bpbreid_amd.metrics import argsort_rows_gpu, evaluate_rank
+    g = torch.Generator().manual_seed(99)
+    for q, G, quant in ((7, 13, 0), (64, 1000, 0), (33, 4097, 16), (5, 1, 0), (3, 70000, 4)):
+        dm = torch.rand(q, G, generator=g)
+        if quant:
+            dm = torch.floor(dm * quant) / quant
+            dm[:, ::7] = 3.5                                   # a block of equal "invalid" entries
+        got = argsort_rows_gpu(dm.to(DEV)).cpu().numpy()
+        assert got.dtype == np.int32 and np.array_equal(got, np.argsort(dm.numpy(), axis=1, kind='stable')), (q, G, quant)
+    q, G = 2048, 20000
+    dm = torch.rand(q, G, generator=g)
+    dm[:, 1000:1100] = dm[:, :100]                             # ties between distant columns
+    d = dm.to(DEV)
+    idx = argsort_rows_gpu(d)
+    srt = torch.gather(d, 1, idx.long())
+    assert bool((srt[:, 1:] >= srt[:, :-1]).all())
+    assert bool((torch.sort(idx.long(), dim=1).values == torch.arange(G, device=DEV)).all())
+    pq = torch.randint(0, 700, (q,), generator=g).numpy()
+    pg = torch.randint(0, 700, (G,), generator=g).numpy()
+    cq = torch.zeros(q, dtype=torch.int64).numpy()
+    cg = torch.ones(G, dtype=torch.int64).numpy()
+    host = evaluate_rank(dm.numpy(), pq, pg, cq, cg, return_indices=True)
+    dev = evaluate_rank(d, pq, pg, cq, cg, return_indices=True)
+    assert np.array_equal(dev['indices'], host['indices']) and np.array_equal(dev['indices'], idx.cpu().numpy())
+    assert np.allclose(dev['cmc'], host['cmc'], atol=1e-6) and abs(dev['mAP'] - host['mAP']) < 1e-9
+
+
 def test_part_distance_full_size_config5_against_oracle_slice():
     """BASELINE config 5's evaluation at FULL size -- 2048 queries x 20 000 gallery entries, P = 9 embeddings (foreground +
     K = 8 parts) of D = 512 with visibility scores -- on the GPU; the CPU oracle restates a 64-query slice (every 32nd query):

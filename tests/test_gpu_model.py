@@ -779,6 +779,48 @@ def test_odd_shapes_forward_loss_and_gradients_against_the_oracle(case):
     assert num / (den1 * den2) ** 0.5 > 0.95, (case, num / (den1 * den2) ** 0.5)
 
 
+@pytest.mark.parametrize('backbone', ['hrnet_w8', 'resnet50'])
+def test_gradient_through_spatial_features_against_the_oracle(backbone):
+    """The concatenated map is a differentiable output of the reference (bpbreid.py:222-259): a loss on `spatial_features` alone
+    must give the oracle's gradients (only backbone parameters receive one), and refuse loudly when the map is not materialised."""
+    from oracle.bpbreid import BPBreID as OracleModel
+    k, n, h, w, ncls = 3, 6, 64, 32, 8
+    cfg = Cm.make_cfg(backbone, k, 32)
+    model = Cm.fill_state_dict_(bpbreid(ncls, config=cfg, pretrained=False)).to(DEV)
+    ref = Cm.fill_state_dict_(OracleModel(ncls, cfg)).double().train()
+    imgs, masks, _ = Cm.synth_batch(n, h, w, k, ncls, instances=1)
+    model.train()
+    model.materialize_spatial_features = True
+    out = model(imgs.to(DEV), external_parts_masks=masks.to(DEV))
+    sp = out[4]
+    g = torch.Generator().manual_seed(5)
+    r = torch.randn(sp.shape, generator=g)
+    (sp * r.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    rout = ref(imgs.double(), masks.double())
+    assert (sp.detach().cpu().double() - rout[4].detach()).abs().max() <= 2e-4 * float(rout[4].detach().abs().max())
+    (rout[4] * r.double()).sum().backward()
+    rp = dict(ref.named_parameters())
+    num = den1 = den2 = 0.0
+    for name, p in model.named_parameters():
+        if rp[name].grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name        # the head received no gradient
+            continue
+        assert p.grad is not None, name
+        rr = rp[name].grad.flatten()
+        sc = float(rr.abs().max().clamp_min(1e-30))
+        gg = p.grad.flatten().double().cpu() / sc
+        rr = rr / sc
+        num += float((gg * rr).sum()); den1 += float((gg * gg).sum()); den2 += float((rr * rr).sum())
+    # (fp32 against the fp64 oracle; on a 64x32 input the deep ResNet stages normalise 48 values per channel, which amplifies
+    #  round-off: measured 0.99987 there, 0.99996 on the HRNet)
+    assert num / (den1 * den2) ** 0.5 > 0.9995, num / (den1 * den2) ** 0.5
+    if backbone.startswith('hrnet'):
+        model.materialize_spatial_features = False
+        out = model(imgs.to(DEV), external_parts_masks=masks.to(DEV))
+        assert out[4] is None
+
+
 def test_single_image_training_batch_is_refused_like_the_reference():
     model = Cm.fill_state_dict_(bpbreid(4, config=Cm.make_cfg('hrnet_w8', 3, 32), pretrained=False)).to(DEV)
     imgs, masks, _ = Cm.synth_batch(1, 64, 32, 3, 4, instances=1)
