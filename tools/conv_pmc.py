@@ -10,22 +10,31 @@ from bpbreid_amd.graph import Net, Act
 
 dev = torch.device('cuda', 0)
 nv.init_device()
-h, w, cin, cout, k = [int(a) for a in sys.argv[1:6]]
-reps = int(sys.argv[6]) if len(sys.argv) > 6 else 20
+BR = [(64, 32, 32, 32, 3), (32, 16, 64, 64, 3), (16, 8, 128, 128, 3), (8, 4, 256, 256, 3)]       # the HRNet-W32 module step
+if sys.argv[1] in ('x2', 'x3', 'x4'):       # python tools/conv_pmc.py x4 [reps]: the grouped launch of the first 2..4 branches
+    shapes = BR[:int(sys.argv[1][1])]
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+else:
+    shapes = [tuple(int(a) for a in sys.argv[1:6])]
+    reps = int(sys.argv[6]) if len(sys.argv) > 6 else 20
+h, w, cin, cout, k = shapes[0]
 N = 64
-flops = 2.0 * N * h * w * k * k * cin * cout
+flops = sum(2.0 * N * h_ * w_ * k_ * k_ * ci_ * co_ for h_, w_, ci_, co_, k_ in shapes)
 net = Net(dev)
 if os.environ.get('CONV_PMC_TILE'):
     net.force_tile = tuple(int(v) for v in os.environ['CONV_PMC_TILE'].split(','))
 if os.environ.get('CONV_PMC_CK'):
     net.force_ck = int(os.environ['CONV_PMC_CK'])
-net.fork(2)          # inside a fork region: the tile policy of the grouped module steps
-x = Act(net, N, h, w, cin)
-x.buf.normal_()
-wt = torch.randn(cout, cin, k, k, device=dev) * 0.05
-wt.grad = torch.zeros_like(wt)
-net.conv(x, wt, 1, k // 2)
-net.join(2)
+net.fork(max(2, len(shapes)))          # inside a fork region: the tile policy of the grouped module steps
+for i, (h_, w_, ci_, co_, k_) in enumerate(shapes):
+    net.set_slot(i)
+    x = Act(net, N, h_, w_, ci_)
+    x.buf.normal_()
+    wt = torch.randn(co_, ci_, k_, k_, device=dev) * 0.05
+    wt.grad = torch.zeros_like(wt)
+    net.conv(x, wt, 1, k_ // 2)
+net.set_slot(0)
+net.join(max(2, len(shapes)))
 net.finalize(False)
 p = net.debug_convs[0][0]
 ops = [i for i, m in enumerate(net.plan_train[2]) if m['label'].startswith('conv_fwd')]
