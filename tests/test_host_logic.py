@@ -3,6 +3,7 @@ emulator of the conv kernels' index algebra), native rank evaluator, optimizer t
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -559,3 +560,21 @@ def test_lowres_head_tables_reproduce_the_materialised_map_statistics():
                         if 0 <= i + di < hs and 0 <= j + dj < ws:
                             gx[:, :, i, j] += float(gh[i, di + 1]) * float(gw[j, dj + 1]) * x[:, :, i + di, j + dj]
         assert torch.allclose((x * gx).sum(dim=(2, 3)), (up * up).sum(dim=(2, 3)), rtol=1e-5, atol=1e-4)
+
+
+def test_roofline_traffic_is_quoted_only_from_a_profile_of_this_build(monkeypatch):
+    """bench.py's `roofline.traffic` comes from the committed PMC passes (counters cannot be read in-process): the file carries the
+    content hash of the kernel sources it was collected on, a mismatch yields null instead of a stale figure, and the committed
+    file belongs to the committed sources (editing csrc/ or the header without re-running tools/profile_all.sh fails here)."""
+    import importlib
+    import json
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module('bench')
+    from bpbreid_amd import build
+    table = json.load(open(os.path.join(ROOT, bench.PMC_FILE)))
+    assert table['_build']['source_id'] == build.source_id(), 'profiles: PMC passes are from another build -- rerun tools/profile_all.sh'
+    got = bench.pmc_traffic('void bpb_conv_s1_kernel<1, 1, 3, 1>(BpbConvS1Prob const*, BpbBlkBegins)')
+    assert got['traffic'] and got['traffic'] > 5e7 and build.source_id() in got['traffic_source']
+    monkeypatch.setattr(build, 'source_id', lambda: 'ffffffffffffffff')
+    stale = bench.pmc_traffic('void bpb_conv_s1_kernel<1, 1, 3, 1>(BpbConvS1Prob const*, BpbBlkBegins)')
+    assert stale['traffic'] is None and 'not quoted' in stale['traffic_source']
