@@ -1,0 +1,732 @@
+// EXPERIMENTAL, NOT PART OF libbpbreid_hip.so (tools/s1_mixed.py links it into a separate library in place of conv_s1.hip).
+// Same kernel as csrc/conv_s1.hip plus ONE addition: a grouped 3x3 launch whose problems differ in the pixel sub-tiles per wave
+// (bpb_conv_s1_mixed_kernel: mt_r = 2, single-level sums, for the shallow wide branches; mt_r = 1 for the deep ones).  Why
+// (tools/s1_trace.py): with the deep chains split, a four-branch launch is two lock-step generations and the
+// second one -- the 1024 four-chunk workgroups of the 32-channel branch -- is latency-bound (23 k cycles of MFMA loop in a 50 k
+// lifetime: prologue, first-chunk wait, epilogue) and moves 8.2 DMA slots per MFMA.  256-pixel tiles halve its workgroups, its
+// fixed costs per MFMA and its DMA traffic (4.25 slots per MFMA); unpadded they still fit four workgroups per CU (39.2 KB), and
+// without the per-chunk accumulator copy (K = 288 / 576: one fp32 chain is within the reference's own noise) the two-tile wave
+// stays under 128 VGPRs.  Unmeasured at the time of writing: round 3's GPU budget was spent.
+//
+// Implicit-GEMM convolution for 3x3 pad-1 and 1x1 pad-0 filters (stride 1: forward and data gradient; stride 2: forward), the
+// lean hot-path kernel: fp32 MFMA (v_mfma_f32_32x32x2_f32), NHWC.  The stride only enters the prologue (which input pixels a
+// tile stages, where a lane's pixel sits in the staged image); the MFMA loop and the epilogue are the same.  90 % of the HRNet-W32 MACs and all of ResNet-50's 1x1 convolutions are of this form:
+//   torchreid/models/hrnet.py:61-64 (conv3x3), :72,:75 (BasicBlock), :104-110 (Bottleneck), :223,:240-250 (fuse 1x1),
+//   torchreid/models/resnet.py:31-49, :119-127 (Bottleneck convs).
+// bpb_conv_igemm_kernel (conv_igemm.hip) stays the general kernel (strides, 7x7, Cin = 3, parity classes of strided dgrad).
+//
+// Why a second kernel: the general one carries a 75-dword descriptor in SGPRs (169 SGPR spills -> v_readlane / v_writelane in
+// every phase), and ~1700 non-MFMA instructions per 32x32 wave tile in its prologue / epilogue (profiles/r01_pmc_sq_*): on the
+// 32- and 64-channel HRNet shapes that is as many issue cycles as the 144-288 MFMAs of the tile.  This kernel fixes the geometry
+// at compile time (R in {1,3}, stride 1, padding R/2), keeps a 40-dword descriptor, computes the tile's output offsets once
+// per register quad and skips the BatchNorm statistics entirely where none are asked for (data gradients, eval).
+//
+// Structure (same proven idioms as the general kernel):
+//   workgroup = 4 waves = ((4 >> lwn) * MT * 32 pixels) x ((NT * 32) << lwn channels); M tile = 2^lTI images x 2^lTH x 2^lTW
+//   per channel chunk CK: halo [halo pixel][CK + 4 pad] and weights [tap][CK/4][N tile][4] arrive in LDS by buffer_load ... lds
+//   DMA, double-buffered against the MFMA loop of the previous chunk (one barrier per chunk); out-of-image halo pixels are
+//   out-of-range offsets that the buffer descriptor zero-fills; one ds_read_b128 = the A (or B) fragment of 4 MFMAs.
+// Launches are grouped: a launch takes up to 16 problems (the branches of an HRNet module step), heaviest workgroups first.
+#include "bpb_common.h"
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define M24(a, b) __umul24((unsigned)(a), (unsigned)(b))
+
+__device__ __forceinline__ unsigned s1_fdiv(unsigned x, unsigned d, unsigned magic)
+{
+    return d == 1 ? x : __umulhi(x, magic);
+}
+
+#ifdef BPB_S1_TRACE
+// Measurement build only (tools/s1_trace.py links it into a separate library; never part of libbpbreid_hip.so): every wave
+// stamps s_memtime at its phase boundaries -- entry, prologue done, first chunk landed, MFMA loop done, exit -- plus where it ran.
+__device__ unsigned long long* g_s1_trace = nullptr;
+// (s_memtime counts shader cycles from a base of its own per CU; s_memrealtime is the chip-wide 100 MHz clock: slots 8, 9)
+#define S1_TR(i) do { if (g_s1_trace && (threadIdx.x & 63) == 0) { unsigned long long* t_ = g_s1_trace + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16; \
+        t_[i] = __builtin_amdgcn_s_memtime(); if ((i) == 0) t_[8] = __builtin_amdgcn_s_memrealtime(); if ((i) == 4) t_[9] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define S1_TR(i) do { } while (0)
+#endif
+// Ablation switches of the measurement build (results are WRONG with any of them; they answer "what does a chunk's time consist
+// of"): 1 no DMA after the first chunk, 2 no barrier after the first chunk, 4 no LDS reads inside the MFMA loop, 8 no per-chunk
+// accumulator bookkeeping, 16 no address updates, 32 DMA offsets without the index arithmetic (lane * 16: what would a free prologue
+// buy?), 64 no epilogue (no stores, no statistics: what would a free epilogue buy?).
+#ifndef S1_ABL
+#define S1_ABL 0
+#endif
+
+// KG = 8-channel k-groups per tap and pipeline stage: channel chunk CK = 8 * KG.  TWOLVL: per-chunk accumulator added to the
+// running one (see the chunk loop); false = one fp32 chain, for the shallow problems of the mixed kernel.
+template <int NT, int MT, int R, int KG, bool TWOLVL>
+__device__ __forceinline__ void s1_body(const BpbConvS1Prob& P, int bid, const int khalf, const int pi)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int T = R * R, PAD = R / 2, CK = 8 * KG, NJ = T * KG;
+    if (P.xr) {
+        // XCD-aware tile map.  The dispatcher places block b on XCD b % 8 (observed, MI355X_MICROARCH.md; a wrong guess costs speed
+        // only), each XCD has its own L2: with consecutive blocks on consecutive tiles every halo row shared by two neighbouring
+        // tiles is fetched by two L2s.  Here the blocks of one XCD walk a contiguous range of this problem's tiles (bijective for
+        // any block count: ranges of q or q + 1 tiles).
+        const int nb = P.n_mtiles * P.n_ntiles, q = nb >> 3, r = nb & 7, f = bid & 7;
+        bid = f * q + min(f, r) + (bid >> 3);
+    }
+
+    if (bid >= 0) S1_TR(10);                   // (descriptor arrived)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int lTW = P.lTW, lTH = P.lTH;
+    const int TWm = (1 << lTW) - 1, THm = (1 << lTH) - 1;
+    // block -> (M tile, N tile), N tile fastest
+    const int mtile = (int)s1_fdiv((unsigned)bid, P.n_ntiles, P.magic_nt);
+    const int ntile = bid - mtile * P.n_ntiles;
+    const int t2 = (int)s1_fdiv((unsigned)mtile, P.tiles_b, P.magic_tb);
+    const int tb = mtile - t2 * P.tiles_b;
+    const int tn = (int)s1_fdiv((unsigned)t2, P.tiles_a, P.magic_ta);
+    const int ta = t2 - tn * P.tiles_a;
+    const int n0 = tn << P.lTI, a0 = ta << lTH, b0 = tb << lTW;
+
+    const int LD = P.LD, HWd = P.HW, HH = P.HH;
+    const int Cin = P.Cin, Cout = P.Cout, cin4 = Cin >> 2;
+    const int lwn = P.lwn;
+    const int wm = wave >> lwn, wni = wave & ((1 << lwn) - 1);
+    const int NTC = (NT * 32) << lwn;            // output channels per workgroup
+    const int lNTC = (NT == 1 ? 5 : 6) + lwn;
+
+    int pixoff[MT];   // byte offset of this lane's pixel (per 32-pixel sub-tile) inside the halo tile, + the k half
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = (wm * MT + mt) * 32 + l31;
+        const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
+        pixoff[mt] = (int)M24(M24(M24(ti, HH) + th * P.S, HWd) + tw * P.S, LD) * 4 + half * 16;
+    }
+    const int cout_l = ntile * NTC + wni * NT * 32 + l31;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    constexpr int lvpp = KG == 1 ? 1 : KG == 2 ? 2 : 3;       // log2(CK / 4)
+    const int npix = (1 << P.lTI) * HH * HWd;
+    const int nch = P.split ? (Cin / CK) >> 1 : Cin / CK;     // chunks of this workgroup (CK divides Cin, evenly with a split: host check)
+    const int cbase = khalf * nch;             // its first chunk
+    // LDS map (16-byte slots): 2 x { halo [halo pixel][LD/4] padded to 256 slots, weights [tap][CK/4][NTC] padded }
+    constexpr int qn = CK >> 2;
+    const int spp = LD >> 2;
+    const int halo_slots = npix * spp;
+    const int halo_reg = (halo_slots + 3) & ~3;          // the weight tile follows the halo directly (64-byte aligned): no padding
+    const int nB = T * qn * NTC;                          // to whole DMA pieces -> 36 instead of 49 KB for the 3x3 / CK = 8 variant,
+    const int bufbytes = (halo_reg + nB) * 16;            // four workgroups per CU instead of three
+    // BatchNorm partials scratch (4 KiB) = the start of the buffer that the LAST chunk does not use: every wave has finished
+    // reading it when it passed the last chunk's barrier and no DMA targets it any more -> no dedicated LDS, no extra barrier
+    const int redbase = (nch & 1) * bufbytes;
+    const int boff_lane = half * NTC * 16 + (wni * NT * 32 + l31) * 16;
+
+    // ---- DMA piece offsets (x and w are < 2 GiB: an "out of range" offset stays out of range after the per-chunk increment)
+    constexpr unsigned DMA_OOB = 0x80000000u;
+    constexpr int DMA_HS = 12, DMA_WS = 12;
+    const int nhs = (halo_slots + 255) >> 8, nws = (nB + 255) >> 8;
+    // lanes of the LAST piece of a region that lie beyond it must not write (they would land in the neighbouring region)
+    const bool hlast = (nhs - 1) * 256 + (int)threadIdx.x < halo_slots;
+    const bool wlast = (nws - 1) * 256 + (int)threadIdx.x < nB;
+    unsigned hofs[DMA_HS], wofs[DMA_WS];
+#pragma unroll
+    for (int k = 0; k < DMA_HS; ++k) {
+        unsigned vo = DMA_OOB;
+        if ((S1_ABL & 32) && k < nhs) vo = (unsigned)((k * 256 + (int)threadIdx.x) * 16);
+        else if (k < nhs) {
+            const int idx = k * 256 + (int)threadIdx.x;
+            const unsigned hp = s1_fdiv((unsigned)idx, spp, P.magic_spp);
+            const int v = idx - (int)M24(hp, spp);
+            const unsigned t = s1_fdiv(hp, HWd, P.magic_hw);
+            const int hc = hp - M24(t, HWd);
+            const unsigned ti = s1_fdiv(t, HH, P.magic_hh);
+            const int hr = t - M24(ti, HH);
+            const int n = n0 + (int)ti, ih = a0 * P.S + hr - PAD, iw = b0 * P.S + hc - PAD;
+            if (idx < halo_slots && v < qn && n < P.N && (unsigned)ih < (unsigned)P.Hi && (unsigned)iw < (unsigned)P.Wi)
+                vo = ((M24(M24(n, P.Hi) + ih, P.Wi) + iw) * (unsigned)Cin + v * 4) * 4u;
+        }
+        hofs[k] = vo;
+        __builtin_amdgcn_sched_barrier(0);   // one piece at a time keeps the register pressure flat
+    }
+    if (hofs[0] != 1u) S1_TR(11);              // (halo offsets done)
+#pragma unroll
+    for (int k = 0; k < DMA_WS; ++k) {
+        unsigned vo = DMA_OOB;
+        if ((S1_ABL & 32) && k < nws) vo = (unsigned)((k * 256 + (int)threadIdx.x) * 16);
+        else if (k < nws) {
+            const int bi = k * 256 + (int)threadIdx.x;
+            const int n = bi & (NTC - 1);
+            const int r = bi >> lNTC;
+            const int q = r & (qn - 1);
+            const int t = r >> lvpp;
+            if (bi < nB && t < T) {
+                const int widx = P.wflip ? T - 1 - t : t;
+                const int co = min(ntile * NTC + n, Cout - 1);     // columns >= Cout are never stored
+                vo = (((unsigned)(widx * cin4 + q) * Cout + co) * 4) * 4u;
+            }
+        }
+        wofs[k] = vo;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)P.x, 0, (int)P.x_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)P.w, 0, (int)P.w_bytes, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    auto dma_issue = [&](int cb, int buf) {
+        char* base = (char*)smem + buf * bufbytes + wave * 1024;     // wave-uniform; lanes land at +16*lane
+        const unsigned incx = (unsigned)(cb * 4);
+#pragma unroll
+        for (int k = 0; k < DMA_HS; ++k)
+            if (k < nhs && (k + 1 < nhs || hlast))
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(base + k * 4096), 16, (int)(hofs[k] + incx), 0, 0, 0);
+        char* wb = base + halo_reg * 16;
+        const unsigned incw = (unsigned)((cb >> 2) * Cout * 16);
+#pragma unroll
+        for (int k = 0; k < DMA_WS; ++k)
+            if (k < nws && (k + 1 < nws || wlast))
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(wb + k * 4096), 16, (int)(wofs[k] + incw), 0, 0, 0);
+    };
+
+    // ---- channel-chunk loop: DMA of chunk c+1 under the MFMAs of chunk c, one barrier per chunk.
+    // The SIMD issues roughly one instruction per 4 cycles over ALL its waves: a 64-cycle MFMA pays for ~15 other instructions
+    // and everything beyond that is lost MFMA time even with other waves resident (profiles/r02_pmc_sq_*: 13 non-MFMA
+    // instructions per MFMA with a run-time tap iterator = 58 % of the peak).  The k-loop is therefore fully unrolled over the
+    // taps and the k-groups of a chunk (template R, KG): the A address of (tap, pixel sub-tile) is one precomputed VGPR + an
+    // immediate, the B address one running VGPR + an immediate -- per k-group 1 VALU + MT + NT ds_read_b128 for 4*MT*NT MFMAs.
+    int apix[T][MT];      // LDS byte offset of this lane's A fragment of tap t (k-group 0), current buffer
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) apix[t][mt] = pixoff[mt] + ((t / R) * HWd + (t % R)) * LD * 4;
+    const int bstride = 2 * NTC * 16;          // bytes of one k-group of the weight tile
+    S1_TR(1);
+    dma_issue(cbase * CK, 0);
+    S1_TR(12);                                 // (first chunk's DMA issued)
+    for (int c = 0; c < nch; ++c) {
+        if (!(S1_ABL & 2) || c == 0) __syncthreads();   // chunk c has landed (the barrier drains vmcnt) and the other buffer is free again
+        if (c == 0) S1_TR(2);
+        if (c + 1 < nch && (!(S1_ABL & 1) || c == 0)) dma_issue((cbase + c + 1) * CK, (c + 1) & 1);
+        const char* lds = (const char*)smem;
+        int bptr = (c & 1) * bufbytes + halo_reg * 16 + boff_lane;
+        // Two-level summation: the MFMAs of one channel chunk (T * CK products per output) accumulate into `cacc`, the chunk sums
+        // are added to `acc` at the end of the chunk.  A single fp32 chain over K = T * Cin (up to 2304) products grows its
+        // round-off like sqrt(K); chunks of 72..288 products + Cin / CK chunk sums keep it at the level of the CPU reference's
+        // blocked sums (tools/diag_noise.py) for 16 * MT * NT extra VALU adds per chunk.
+        // (NA = 2 interleaved accumulator sets for the single-tile wave -- consecutive MFMAs independent of each other -- measured
+        // no gain, tools/s1_trace.py round 3: S1_NA of the measurement build.)
+#ifndef S1_NA
+#define S1_NA 1
+#endif
+        constexpr int NA = (MT * NT == 1) ? S1_NA : 1;
+        f32x16 cacc[NA][MT][NT];
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cacc[a][mt][nt][r] = 0.f;
+        // ping-pong operand sets: the LDS reads of k-group j+1 are in flight while the 4*MT*NT MFMAs of k-group j run
+        f32x4 fa[2][MT], fb[2][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) fa[0][mt] = *(const f32x4*)(lds + apix[0][mt]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) fb[0][nt] = *(const f32x4*)(lds + bptr + nt * 512);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (j + 1 < NJ && !(S1_ABL & 4)) {
+                bptr += bstride;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) fa[(j + 1) & 1][mt] = *(const f32x4*)(lds + apix[(j + 1) / KG][mt] + ((j + 1) % KG) * 32);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) fb[(j + 1) & 1][nt] = *(const f32x4*)(lds + bptr + nt * 512);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the reads of k-group j+1 ahead of the MFMAs of k-group j
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        if constexpr (TWOLVL)
+                            cacc[i & (NA - 1)][mt][nt] = MFMA32(fa[(S1_ABL & 4) ? 0 : (j & 1)][mt][i], fb[(S1_ABL & 4) ? 0 : (j & 1)][nt][i], cacc[i & (NA - 1)][mt][nt]);
+                        else
+                            acc[mt][nt] = MFMA32(fa[(S1_ABL & 4) ? 0 : (j & 1)][mt][i], fb[(S1_ABL & 4) ? 0 : (j & 1)][nt][i], acc[mt][nt]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // next chunk lives in the other buffer
+        const int delta = (c & 1) ? -bufbytes : bufbytes;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) if (!(S1_ABL & 16)) apix[t][mt] += delta;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (TWOLVL && (!(S1_ABL & 8) || c + 1 == nch)) acc[mt][nt][r] += NA == 2 ? cacc[0][mt][nt][r] + cacc[NA - 1][mt][nt][r] : cacc[0][mt][nt][r];
+    }
+
+    S1_TR(3);
+    if (P.split) {
+        // hand-over of the first half's accumulators (MI355X_MICROARCH.md, inter-workgroup visibility: the per-XCD L2s are not
+        // coherent with each other): write-through (sc1) 16-byte stores in register layout -> every wave drains its stores ->
+        // barrier -> relaxed agent-scope flag; the consumer polls relaxed, takes ONE agent acquire, reads with sc1 loads.
+        auto uniform = [](const void* p_) {
+            const unsigned long long u = (unsigned long long)p_;
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+            return (void*)(((unsigned long long)hi << 32) | lo);
+        };
+        const BpbS1Split* sp = P.split;
+        float* part = (float*)uniform(sp->part);
+        int* flags = (int*)uniform(sp->flags);
+        const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)part, 0, (int)sp->part_bytes, 0x00020000);
+        constexpr int SC1 = 16;
+        using b128_t = decltype(__builtin_amdgcn_raw_buffer_load_b128(rp, 0, 0, 0));    // (the builtins' own 16-byte vector type)
+        const unsigned pofs = (unsigned)((bid * (MT * NT * 4) * 256 + (int)threadIdx.x) * 16);
+        if (khalf == 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = {acc[mt][nt][q * 4 + 0], acc[mt][nt][q * 4 + 1], acc[mt][nt][q * 4 + 2], acc[mt][nt][q * 4 + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(b128_t, v), rp, (int)(pofs + (unsigned)(((mt * NT + nt) * 4 + q) * 4096)), 0, SC1);
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_store(flags + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef BPB_S1_TRACE
+            S1_TR(4);
+            if (g_s1_trace && (threadIdx.x & 63) == 0) {
+                unsigned long long* t = g_s1_trace + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+                t[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+                t[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+                t[7] = (unsigned long long)pi | 0x100;       // (first half of a K split)
+            }
+#endif
+            return;
+        }
+        if (threadIdx.x == 0) {
+            int spins = 0;          // (bounded: a lost hand-over must not hang the device; the time-out mark is checked by the host tools)
+            while (__hip_atomic_load(flags + bid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(8);
+            if (spins >= (1 << 20)) __hip_atomic_store(flags + P.n_mtiles * P.n_ntiles, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(flags + bid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    v[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, (int)(pofs + (unsigned)(((mt * NT + nt) * 4 + q) * 4096)), 0, SC1));
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[mt][nt][q * 4 + e] += v[q][e];
+            }
+    }
+    if (S1_ABL & 64) {
+        if (acc[0][0][0] == 12345.678f) P.y[threadIdx.x] = acc[0][0][1];      // (keeps the accumulators alive)
+        S1_TR(4);
+        return;
+    }
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31 (channel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+    // Stores (and the loads of the accumulate mode) go through a buffer descriptor; an invalid pixel adds 2^31 and an invalid
+    // channel 2^30 to the 32-bit offset, so every invalid combination is dropped by the hardware (y is <= 1 GiB, host check).
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)P.y, 0, (int)P.y_bytes, 0x00020000);
+    const unsigned PIX_OOB = 0x80000000u, CH_OOB = 0x40000000u;
+    const bpb_gcf gbias = (bpb_gcf)P.bias;
+    float bias_v[NT];
+    unsigned cofs[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const bool cv = cout_l + nt * 32 < Cout;
+        bias_v[nt] = (gbias && cv) ? gbias[cout_l + nt * 32] : 0.f;
+        cofs[nt] = cv ? (unsigned)(nt * 128) : CH_OOB;
+    }
+    // accumulate: y += result (data gradients); res: y = act(result + bias + res) with res another tensor of y's shape (eval plan:
+    // the residual add of a block rides in the epilogue of its last convolution) -- both read 16 values per register tile
+    const bool accum = P.accumulate != 0 || P.res != nullptr, relu = P.relu != 0, do_stats = P.stats != nullptr;
+    const __amdgpu_buffer_rsrc_t rold = P.res ? __builtin_amdgcn_make_buffer_rsrc((void*)P.res, 0, (int)P.y_bytes, 0x00020000) : ry;
+    const int pstride = Cout * 4;
+    // bnb: this launch writes the FINAL gradient of a fuse output O; the per-tile partials become (sum G, sum G * xhat) of the
+    // BatchNorm behind O (G = v where O > 0, xhat = (src - mean) * invstd), which saves the separate reduce pass over the gradient
+    // and the BatchNorm input (csrc/bn_act.hip, bpb_term_bwd mode 1).
+    constexpr bool BNB = true;
+    const bool bn_bwd = do_stats && P.bnb != nullptr;
+    const float* bn_out = nullptr;
+    const float* bn_src = nullptr;
+    float bn_mu[NT], bn_is[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bn_mu[nt] = bn_is[nt] = 0.f;
+    if (bn_bwd) {
+        // the record is read once per wave; its pointers must sit in SGPRs (buffer descriptors)
+        auto uniform_ptr = [](const void* p_) {
+            const unsigned long long u = (unsigned long long)p_;
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+            return (const float*)(((unsigned long long)hi << 32) | lo);
+        };
+        const BpbS1BnBwd* bp = P.bnb;
+        bn_out = uniform_ptr(bp->out);
+        bn_src = uniform_ptr(bp->src);
+        const float* mean_p = uniform_ptr(bp->mean);
+        const float* invstd_p = uniform_ptr(bp->invstd);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            if (cout_l + nt * 32 < Cout) {
+                bn_mu[nt] = mean_p[cout_l + nt * 32];
+                bn_is[nt] = invstd_p[cout_l + nt * 32];
+            }
+    }
+    const __amdgpu_buffer_rsrc_t rbs = __builtin_amdgcn_make_buffer_rsrc((void*)(bn_src ? bn_src : P.y), 0, (int)P.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbo = __builtin_amdgcn_make_buffer_rsrc((void*)(bn_out ? bn_out : P.y), 0, (int)P.y_bytes, 0x00020000);
+    double ssum[NT], ssq[NT];   // BatchNorm partials accumulate in fp64 from the first element on: fp32 partial sums (even of only 16
+                                // values) measurably raise the error of the gradients through the ~320 BatchNorm layers
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        ssum[nt] = 0.0;
+        ssq[nt] = 0.0;
+    }
+    // ---- forward epilogue through an LDS transpose (P.tstore; single-tile waves).  In the MFMA layout a lane owns ONE channel of
+    // 16 pixels: 16 four-byte stores (and 16 loads of the residual) per lane, two 128-byte segments per instruction -- for the
+    // 32-channel branch these are 40 % of the wave's memory instructions (16 of 16 + 4 x 6), and the memory pipe of the CU, not the
+    // MFMA pipe, is what the short workgroups wait for (tools/s1_trace.py ablation 64: a launch without epilogues is 8-9 %
+    // shorter).  Here the wave writes its 32 x 32 tile into the staging buffer the last chunk did not use and reads it back as
+    // [pixel][4 channels]: 4 sixteen-byte stores (+ 4 loads) per lane, 4 offsets instead of 16.
+    bool tdone = false;
+    if constexpr (MT == 1 && NT == 1) {
+        if (P.tstore) {
+            tdone = true;
+            const bool has_res = P.res != nullptr;
+            float* tile = (float*)((char*)smem + redbase) + wave * 1024;       // [32 pixels][32 channels] of this wave
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[0][0][r] + bias_v[0];
+                if (relu && !has_res) v = fmaxf(v, 0.f);
+                if (do_stats) {
+                    // pixels of a ragged tile beyond the image do not count (their taps read real neighbours); padding channels are
+                    // never stored below.  fp64 from the first element on, as in the per-register path
+                    const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
+                    const double dv = (n0 + ti < P.N && a0 + th < P.H && b0 + tw < P.W) ? (double)v : 0.0;
+                    ssum[0] += dv;
+                    ssq[0] += dv * dv;
+                }
+                tile[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = v;
+            }
+            const int trow = lane >> 3, cq = lane & 7;
+            const int cout_t = ntile * NTC + wni * 32 + cq * 4;
+            const bool cvq = cout_t < Cout;                                   // (Cout % 4 == 0: a quad is valid or not as a whole)
+            using b128_t = decltype(__builtin_amdgcn_raw_buffer_load_b128(ry, 0, 0, 0));
+            f32x4 tv[4];
+            unsigned toff[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                tv[i] = *(const f32x4*)(tile + (trow + 8 * i) * 32 + cq * 4);
+                const int m = wm * 32 + trow + 8 * i;
+                const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
+                const int n = n0 + ti, a = a0 + th, b = b0 + tw;
+                const bool pv = (n < P.N) && (a < P.H) && (b < P.W) && cvq;
+                toff[i] = pv ? M24(M24(M24(n, P.H) + a, P.W) + b, pstride) + (unsigned)(cout_t * 4) : PIX_OOB;
+            }
+            if (has_res) {
+                f32x4 ov[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ov[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rold, (int)toff[i], 0, 0));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = tv[i][e] + ov[i][e];
+                        tv[i][e] = relu ? fmaxf(v, 0.f) : v;
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(b128_t, tv[i]), ry, (int)toff[i], 0, 0);
+            if (do_stats) __syncthreads();        // the partial sums below reuse the tiles' memory
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        if (tdone) break;
+        unsigned offs[16];
+        if (lTW >= 2) {
+            // tile width >= 4: the four rows (r & 3) of a register quad are four consecutive pixels of one image row
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int m = (wm * MT + mt) * 32 + 8 * rq + 4 * half;
+                const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
+                const int n = n0 + ti, a = a0 + th, b = b0 + tw;
+                const bool pq = (n < P.N) && (a < P.H);
+                const unsigned qoff = M24(M24(M24(n, P.H) + a, P.W) + b, pstride) + (unsigned)(cout_l * 4);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) offs[rq * 4 + jj] = (pq && b + jj < P.W) ? qoff + (unsigned)(jj * pstride) : PIX_OOB;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
+                const int n = n0 + ti, a = a0 + th, b = b0 + tw;
+                const bool pv = (n < P.N) && (a < P.H) && (b < P.W);
+                offs[r] = pv ? M24(M24(M24(n, P.H) + a, P.W) + b, pstride) + (unsigned)(cout_l * 4) : PIX_OOB;
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float old[16];
+            if (accum) {   // all sixteen loads in flight before the first add
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rold, (int)(offs[r] + cofs[nt]), 0, 0));
+            }
+            if (BNB && bn_bwd) {
+                // ---- data gradient + BatchNorm-backward partials.  (out-of-range elements read 0: xhat finite, mask false)
+                float bs[16], bo[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    bs[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbs, (int)(offs[r] + cofs[nt]), 0, 0));
+                if (bn_out) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        bo[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbo, (int)(offs[r] + cofs[nt]), 0, 0));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) bo[r] = (offs[r] + cofs[nt]) < CH_OOB ? 1.f : 0.f;
+                }
+                // backward sums: fp32 over the 16 values of the register tile, fp64 from there on (the separate reduce pass keeps
+                // fp32 running sums over 64 pixels)
+                float fs = 0.f, fq = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[mt][nt][r];
+                    if (accum) v += old[r];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, (int)(offs[r] + cofs[nt]), 0, 0);
+                    const float g = bo[r] > 0.f ? v : 0.f;
+                    fs += g;
+                    fq += g * ((bs[r] - bn_mu[nt]) * bn_is[nt]);
+                }
+                ssum[nt] += (double)fs;
+                ssq[nt] += (double)fq;
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned off = offs[r] + cofs[nt];
+                float v = acc[mt][nt][r] + bias_v[nt];
+                if (accum) v += old[r];
+                if (relu) v = fmaxf(v, 0.f);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, (int)off, 0, 0);
+                if (do_stats) {
+                    const double dv = off < CH_OOB ? (double)v : 0.0;
+                    ssum[nt] += dv;
+                    ssq[nt] += dv * dv;
+                }
+            }
+        }
+    }
+    if (do_stats) {   // per-tile BatchNorm partials, combined in fp64 in a fixed order (deterministic: no atomics)
+        double* red = (double*)((char*)smem + redbase);   // [wave][NT*32][2]
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const double s = ssum[nt] + __shfl_xor(ssum[nt], 32);
+            const double q = ssq[nt] + __shfl_xor(ssq[nt], 32);
+            if (half == 0) {
+                red[((wave * NT + nt) * 32 + l31) * 2 + 0] = s;
+                red[((wave * NT + nt) * 32 + l31) * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < NTC) {
+            const int cw = threadIdx.x / (NT * 32);            // which wave column owns this channel
+            const int nt = (threadIdx.x >> 5) % NT, cc = threadIdx.x & 31;
+            const int co = ntile * NTC + (int)threadIdx.x;
+            if (co < Cout) {
+                double s = 0.0, q = 0.0;
+                for (int wr = 0; wr < (4 >> lwn); ++wr) {           // fixed order over the wave rows
+                    const int w = (wr << lwn) + cw;
+                    s += red[((w * NT + nt) * 32 + cc) * 2 + 0];
+                    q += red[((w * NT + nt) * 32 + cc) * 2 + 1];
+                }
+                double* gs = P.stats;
+                gs[((size_t)mtile * 2 + 0) * Cout + co] = s;
+                gs[((size_t)mtile * 2 + 1) * Cout + co] = q;
+            }
+        }
+    }
+#ifdef BPB_S1_TRACE
+    __builtin_amdgcn_s_waitcnt(0);            // (vmcnt / lgkmcnt 0: the stores have been accepted)
+    S1_TR(4);
+    if (g_s1_trace && (threadIdx.x & 63) == 0) {
+        unsigned long long* t = g_s1_trace + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+        t[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
+        t[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
+        t[7] = (unsigned long long)pi;
+    }
+#endif
+}
+
+// the kernels: block -> (problem, block of the problem, K half), then the tile body
+#define S1_PREAMBLE                                                                                          \
+    S1_TR(0);                                                                                                \
+    int bid = blockIdx.x;                                                                                    \
+    const int pi = bpb_find_problem(bb, bid);                                                                \
+    const BpbConvS1Prob P = probs[pi];                                                                       \
+    bid -= P.blk_begin;                                                                                      \
+    /* K split over two workgroups per tile (BpbS1Split): first halves first in the grid, see csrc/conv_s1.hip */ \
+    int khalf = 0;                                                                                           \
+    if (P.split) {                                                                                           \
+        khalf = bid >= P.n_mtiles * P.n_ntiles;                                                              \
+        bid -= khalf * P.n_mtiles * P.n_ntiles;                                                              \
+    }
+
+template <int NT, int MT, int R, int KG>
+__global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob* __restrict__ probs, BpbBlkBegins bb)
+{
+    S1_PREAMBLE
+    s1_body<NT, MT, R, KG, true>(P, bid, khalf, pi);
+}
+
+// problems of one launch with ONE or TWO 32-pixel sub-tiles per wave (P.mt_r): four waves per SIMD need <= 128 VGPRs
+template <int R, int KG>
+__global__ __launch_bounds__(256, 4) void bpb_conv_s1_mixed_kernel(const BpbConvS1Prob* __restrict__ probs, BpbBlkBegins bb)
+{
+    S1_PREAMBLE
+    if (P.mt_r == 2) s1_body<1, 2, R, KG, false>(P, bid, khalf, pi);
+    else s1_body<1, 1, R, KG, true>(P, bid, khalf, pi);
+}
+
+// ------------------------------------ C ABI ------------------------------------------
+static int conv_s1_lds_bytes(const BpbConvS1Prob& p)
+{
+    const int npix = (1 << p.lTI) * p.HH * p.HW;
+    const int halo_reg = (npix * (p.LD / 4) + 3) & ~3;
+    const int nB = p.R * p.R * (p.CK / 4) * ((p.nt * 32) << p.lwn);
+    const int l = 2 * (halo_reg + nB) * 16;
+    return l < 8192 ? 8192 : l;          // (the BatchNorm partial scratch of the epilogue aliases one buffer: <= 4 KiB)
+}
+
+extern "C" {
+
+#ifdef BPB_S1_TRACE
+int bpb_conv_s1_set_trace(unsigned long long* buf)
+{
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_s1_trace), &buf, sizeof(buf));
+    return e == hipSuccess ? 0 : bpb_set_error((int)e, "bpb_conv_s1_set_trace: %s", hipGetErrorString(e));
+}
+#endif
+
+int bpb_conv_s1_init(void)
+{
+#define BPB_ATTR(K)                                                                                                  \
+    {                                                                                                                \
+        hipError_t e = hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+        if (e != hipSuccess) return bpb_set_error((int)e, "bpb_conv_s1_init: %s", hipGetErrorString(e));              \
+    }
+#define BPB_ATTR_K(NT, MT, RR) BPB_ATTR((bpb_conv_s1_kernel<NT, MT, RR, 1>)) BPB_ATTR((bpb_conv_s1_kernel<NT, MT, RR, 2>)) BPB_ATTR((bpb_conv_s1_kernel<NT, MT, RR, 4>))
+    BPB_ATTR_K(1, 1, 3) BPB_ATTR_K(1, 2, 3) BPB_ATTR_K(2, 1, 3) BPB_ATTR_K(2, 2, 3)
+    BPB_ATTR_K(1, 1, 1) BPB_ATTR_K(1, 2, 1) BPB_ATTR_K(2, 1, 1) BPB_ATTR_K(2, 2, 1)
+    BPB_ATTR((bpb_conv_s1_mixed_kernel<3, 1>)) BPB_ATTR((bpb_conv_s1_mixed_kernel<3, 2>)) BPB_ATTR((bpb_conv_s1_mixed_kernel<3, 4>))
+#undef BPB_ATTR_K
+#undef BPB_ATTR
+    return 0;
+}
+
+// Grouped launch of stride-1 convolution problems (descriptors in device memory, `h_probs` = host copy for validation).
+// All problems of a launch share the kernel variant (nt, mt_r, R, CK).  Replaces aten::conv2d / conv backward-input for
+// stride-1 3x3 and 1x1 convolutions on the path.
+int bpb_conv_s1(const BpbConvS1Prob* d_probs, const BpbConvS1Prob* h_probs, int nprobs, hipStream_t stream)
+{
+    BPB_REQUIRE(nprobs >= 1 && nprobs <= 16, "bpb_conv_s1: nprobs=%d out of range", nprobs);
+    int nblk = 0, lds = 0;
+    const int nt = h_probs[0].nt, mt = h_probs[0].mt_r, R = h_probs[0].R, ck = h_probs[0].CK;
+    BPB_REQUIRE((nt == 1 || nt == 2) && (mt == 1 || mt == 2) && (R == 1 || R == 3), "bpb_conv_s1: variant nt=%d mt=%d R=%d", nt, mt, R);
+    // (experimental) 3x3 problems of single-column waves may differ in the pixel sub-tiles per wave: bpb_conv_s1_mixed_kernel
+    bool mixed = false, any2 = false;
+    for (int i = 0; i < nprobs; ++i) mixed = mixed || h_probs[i].mt_r != mt, any2 = any2 || h_probs[i].mt_r == 2;
+    BPB_REQUIRE(!mixed || (R == 3 && nt == 1), "bpb_conv_s1: problems with different mt_r share a launch only for 3x3, nt = 1");
+    // every 3x3 launch of single-column waves with a two-tile problem runs on the mixed kernel (106 instead of 137 VGPRs: four
+    // waves per SIMD; single-level sums for the two-tile problems)
+    mixed = R == 3 && nt == 1 && any2;
+    for (int i = 0; i < nprobs; ++i) {
+        const BpbConvS1Prob& p = h_probs[i];
+        const int mt = p.mt_r;                       // (per problem from here on)
+        BPB_REQUIRE(mt == 1 || mt == 2, "bpb_conv_s1: mt_r=%d", mt);
+        BPB_REQUIRE(p.nt == nt && p.R == R && p.CK == ck, "bpb_conv_s1: mixed kernel variants in one group");
+        BPB_REQUIRE(p.Cin % 8 == 0 && p.Cout % 4 == 0, "bpb_conv_s1: Cin=%d must be a multiple of 8, Cout=%d of 4", p.Cin, p.Cout);
+        BPB_REQUIRE((p.CK == 8 || p.CK == 16 || p.CK == 32) && p.Cin % p.CK == 0 && (p.LD == p.CK + 4 || p.LD == p.CK),
+                    "bpb_conv_s1: bad channel chunk CK=%d (LD=%d) for Cin=%d", p.CK, p.LD, p.Cin);
+        BPB_REQUIRE(p.lwn == 0 || p.lwn == 1, "bpb_conv_s1: lwn=%d", p.lwn);
+        BPB_REQUIRE((1 << (p.lTI + p.lTH + p.lTW)) == (4 >> p.lwn) * mt * 32, "bpb_conv_s1: M tile / wave layout mismatch");
+        BPB_REQUIRE(p.S == 1 || p.S == 2, "bpb_conv_s1: stride %d", p.S);
+        BPB_REQUIRE(p.res == nullptr || p.accumulate == 0, "bpb_conv_s1: a residual operand excludes the accumulate mode");
+        BPB_REQUIRE(p.bnb == nullptr || (p.stats != nullptr && p.relu == 0 && p.res == nullptr && p.bias == nullptr),
+                    "bpb_conv_s1: the BatchNorm-backward partials need `stats` and a plain (or accumulating) data-gradient epilogue");
+        BPB_REQUIRE(p.HH == ((1 << p.lTH) - 1) * p.S + R && p.HW == ((1 << p.lTW) - 1) * p.S + R, "bpb_conv_s1: halo extent mismatch");
+        BPB_REQUIRE(p.H == (p.Hi + 2 * (R / 2) - R) / p.S + 1 && p.W == (p.Wi + 2 * (R / 2) - R) / p.S + 1 && (p.S == 1 || p.wflip == 0),
+                    "bpb_conv_s1: output %dx%d does not follow from input %dx%d (stride %d)", p.H, p.W, p.Hi, p.Wi, p.S);
+        BPB_REQUIRE(p.x_bytes > 0 && p.w_bytes > 0 && p.y_bytes > 0 && p.x_bytes < 0x80000000u && p.w_bytes < 0x80000000u &&
+                        p.y_bytes <= 0x40000000u,
+                    "bpb_conv_s1: tensors addressed through a buffer descriptor must be < 2 GiB (y <= 1 GiB)");
+        BPB_REQUIRE((double)p.N * p.H * p.W < 16777216.0 && (double)p.N * p.Hi * p.Wi < 16777216.0 && p.Cout * 4 < 16777216,
+                    "bpb_conv_s1: 24-bit index arithmetic overflow");
+        BPB_REQUIRE(((uintptr_t)p.x & 15) == 0 && ((uintptr_t)p.w & 15) == 0, "bpb_conv_s1: x/w must be 16-byte aligned");
+        BPB_REQUIRE(p.tiles_a == bpb_cdiv(p.H, 1 << p.lTH) && p.tiles_b == bpb_cdiv(p.W, 1 << p.lTW) &&
+                        p.n_mtiles == bpb_cdiv(p.N, 1 << p.lTI) * p.tiles_a * p.tiles_b &&
+                        p.n_ntiles == bpb_cdiv(p.Cout, (32 * nt) << p.lwn),
+                    "bpb_conv_s1: tile counts mismatch");
+        BPB_REQUIRE(p.blk_begin == nblk, "bpb_conv_s1: blk_begin mismatch");
+        BPB_REQUIRE(p.tstore == 0 || (nt == 1 && mt == 1 && p.accumulate == 0 && p.bnb == nullptr && (p.stats == nullptr || p.res == nullptr) &&
+                                      conv_s1_lds_bytes(p) >= 2 * 16384),
+                    "bpb_conv_s1: the transposed epilogue is for plain forward problems of single-tile waves with >= 16 KiB staging buffers");
+        BPB_REQUIRE(p.split == nullptr || ((p.Cin / p.CK) % 2 == 0 && (double)p.n_mtiles * p.n_ntiles * mt * nt * 16384.0 < 2147483648.0),
+                    "bpb_conv_s1: a K split needs an even number of channel chunks (Cin=%d, CK=%d) and < 2 GiB of hand-over space", p.Cin, p.CK);
+        const int npix = (1 << p.lTI) * p.HH * p.HW;
+        const int halo_pad = (npix * (p.LD / 4) + 255) & ~255;
+        const int b_pad = (R * R * (p.CK / 4) * ((nt * 32) << p.lwn) + 255) & ~255;
+        BPB_REQUIRE(halo_pad <= 12 * 256 && b_pad <= 12 * 256, "bpb_conv_s1: more than 12 DMA pieces per thread (halo %d, weights %d slots)",
+                    halo_pad, b_pad);
+        nblk += p.n_mtiles * p.n_ntiles * (p.split ? 2 : 1);
+        const int l = conv_s1_lds_bytes(p);
+        lds = l > lds ? l : lds;
+    }
+    BPB_REQUIRE(lds <= 160 * 1024, "bpb_conv_s1: needs %d B of LDS", lds);
+    if (nblk == 0) return 0;
+    const BpbBlkBegins bb = bpb_blk_begins(h_probs, nprobs);
+    if (mixed) {
+        if (ck == 8) hipLaunchKernelGGL((bpb_conv_s1_mixed_kernel<3, 1>), dim3(nblk), dim3(256), lds, stream, d_probs, bb);
+        else if (ck == 16) hipLaunchKernelGGL((bpb_conv_s1_mixed_kernel<3, 2>), dim3(nblk), dim3(256), lds, stream, d_probs, bb);
+        else hipLaunchKernelGGL((bpb_conv_s1_mixed_kernel<3, 4>), dim3(nblk), dim3(256), lds, stream, d_probs, bb);
+        BPB_LAUNCH_OK();
+        return 0;
+    }
+#define BPB_S1_LAUNCH(NT, MT, RR, KG) \
+    hipLaunchKernelGGL((bpb_conv_s1_kernel<NT, MT, RR, KG>), dim3(nblk), dim3(256), lds, stream, d_probs, bb)
+#define BPB_S1_K(NT, MT, RR) \
+    do { if (ck == 8) { BPB_S1_LAUNCH(NT, MT, RR, 1); } else if (ck == 16) { BPB_S1_LAUNCH(NT, MT, RR, 2); } else { BPB_S1_LAUNCH(NT, MT, RR, 4); } } while (0)
+#define BPB_S1_R(NT, MT) \
+    do { if (R == 3) { BPB_S1_K(NT, MT, 3); } else { BPB_S1_K(NT, MT, 1); } } while (0)
+    if (nt == 1 && mt == 1) BPB_S1_R(1, 1);
+    else if (nt == 1) BPB_S1_R(1, 2);
+    else if (mt == 1) BPB_S1_R(2, 1);
+    else BPB_S1_R(2, 2);
+#undef BPB_S1_R
+#undef BPB_S1_K
+#undef BPB_S1_LAUNCH
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+}   // extern "C"

@@ -327,6 +327,10 @@ class Net:
                 return _cdiv(n, ti_) * _cdiv(h, th_) * _cdiv(w, tw_) * _cdiv(cout, (32 * nt_) << lwn_)
             if r == 3 and in_region:
                 mt_r, nt, lwn = 1, 1, 0
+                # (experimental, needs the library of tools/s1_mixed.py: csrc/experimental/conv_s1_mixed.hip) the shallow wide
+                # branches take two pixel sub-tiles per wave and still share the launch of the deep ones
+                if os.environ.get('BPB_S1_MIXED', '0') == '1' and k2 <= int(os.environ.get('BPB_S1_MIXED_MAX', '288')) and wgs(2, 1, 0) >= 256:
+                    mt_r = 2
             elif r == 3:
                 # a launch of its own: the largest wave tile that still gives two workgroups per CU (tools/s1_sweep.py:
                 # 64->64 @64x32 118 TFLOP/s with 64x64 wave tiles, 128->128 @16x8 only 31 with them but 90 with 32x32)
@@ -520,7 +524,8 @@ class Net:
     def _conv_rec(self, prob, label):
         """Launch record of one convolution problem (either kernel)."""
         if isinstance(prob, ConvS1Prob):
-            kind, key = nv.OP_CONV_S1, ('s1', prob.nt, prob.mt_r, prob.R, prob.CK)
+            mixed = os.environ.get('BPB_S1_MIXED', '0') == '1' and prob.R == 3 and prob.nt == 1 and prob.lwn == 0
+            kind, key = nv.OP_CONV_S1, ('s1', prob.nt, 'any' if mixed else prob.mt_r, prob.R, prob.CK)
             variant = 'bpb_conv_s1_kernel<%d,%d,%d,%d>' % (prob.nt, prob.mt_r, prob.R, prob.CK // 8)
             npix, taps, cin_in = prob.N * prob.H * prob.W, prob.R * prob.R, prob.N * prob.H * prob.W * prob.Cin
             blocks = prob.n_mtiles * prob.n_ntiles
@@ -908,14 +913,15 @@ class Net:
         against a slot-throughput bound of 158 k).  Problems with >= BPB_S1_SPLIT_RATIO (default 8, 0: never) times the
         lightest problem's MFMAs per wave take two workgroups per tile."""
         ratio = float(os.environ.get('BPB_S1_SPLIT_RATIO', '8'))
-        lightest = min(r_.work for r_ in g)
+        chain = lambda r_: r_.work / (r_.desc.mt_r * r_.desc.nt)       # MFMAs of ONE accumulator chain (work counts all tiles of a wave)
+        lightest = min(chain(r_) for r_ in g)
         for r_ in g:
             d = r_.desc
             ntiles = d.n_mtiles * d.n_ntiles
             if d.split:                                   # (a record frozen into a second plan keeps its split)
                 r_.blocks = 2 * ntiles
                 continue
-            if ratio <= 0 or len(g) < 2 or r_.work < ratio * lightest or (d.Cin // d.CK) % 2 or d.Cin // d.CK < 8:
+            if ratio <= 0 or len(g) < 2 or chain(r_) < ratio * lightest or (d.Cin // d.CK) % 2 or d.Cin // d.CK < 8:
                 continue
             part = torch.empty(ntiles * d.mt_r * d.nt * 4 * 256 * 4, device=self.device, dtype=torch.float32)
             flags = torch.zeros(ntiles + 1, device=self.device, dtype=torch.int32)

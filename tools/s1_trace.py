@@ -18,11 +18,16 @@ NA = os.environ.get('S1_NA', '1')
 tag = '' if (ABL, NA) == ('0', '1') else '_abl%s_na%s' % (ABL, NA)
 trace_lib = os.path.join(objdir, 'libbpbreid_hip_trace%s.so' % tag)
 trace_obj = os.path.join(objdir, 'conv_s1_trace%s.o' % tag)
-src = os.path.join(B.CSRC, 'conv_s1.hip')
+src = os.environ.get('S1_TRACE_SRC') or os.path.join(B.CSRC, 'conv_s1.hip')       # (S1_TRACE_SRC: csrc/experimental/conv_s1_mixed.hip)
+if os.environ.get('S1_TRACE_SRC'):
+    tag += '_' + os.path.splitext(os.path.basename(src))[0]
+    trace_lib = os.path.join(objdir, 'libbpbreid_hip_trace%s.so' % tag)
+    trace_obj = os.path.join(objdir, 'conv_s1_trace%s.o' % tag)
 B.build()
 if not os.path.exists(trace_obj) or os.path.getmtime(trace_obj) < os.path.getmtime(src):
     subprocess.check_call([os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-x', 'hip',
-                           '-DBPB_S1_TRACE', '-DS1_ABL=' + ABL, '-DS1_NA=' + NA, '-c', src, '-o', trace_obj, '-I', B.CSRC, '-Wno-unused-value'])
+                           '-DBPB_S1_TRACE', '-DS1_ABL=' + ABL, '-DS1_NA=' + NA, '-c', src, '-o', trace_obj, '-I', B.CSRC,
+                           '-I', os.path.join(ROOT, 'include'), '-Wno-unused-value'])
 objs = [os.path.join(objdir, s.rsplit('.', 1)[0] + '.o') for s in B.SOURCES if s != 'conv_s1.hip'] + [trace_obj]
 if not os.path.exists(trace_lib) or any(os.path.getmtime(o) > os.path.getmtime(trace_lib) for o in objs):
     subprocess.check_call([os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', trace_lib] + objs)
