@@ -329,7 +329,7 @@ class Net:
                 mt_r, nt, lwn = 1, 1, 0
                 # (experimental, needs the library of tools/s1_mixed.py: csrc/experimental/conv_s1_mixed.hip) the shallow wide
                 # branches take two pixel sub-tiles per wave and still share the launch of the deep ones
-                if os.environ.get('BPB_S1_MIXED', '0') == '1' and k2 <= int(os.environ.get('BPB_S1_MIXED_MAX', '288')) and wgs(2, 1, 0) >= 256:
+                if os.environ.get('BPB_S1_MIXED', '0') == '1' and k2 <= int(os.environ.get('BPB_S1_MIXED_MAX', '288')) and wgs(2, 1, 0) >= int(os.environ.get('BPB_S1_MIXED_MINWG', '256')):
                     mt_r = 2
             elif r == 3:
                 # a launch of its own: the largest wave tile that still gives two workgroups per CU (tools/s1_sweep.py:
