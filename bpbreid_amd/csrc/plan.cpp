@@ -26,6 +26,62 @@ extern "C" int bpb_plan_run(const BpbPlanOp* ops, int nops, hipStream_t stream)
     return 0;
 }
 
+// Two-stream variant (round 4).  Records whose i[10] is 1 -- the weight-gradient launches, their slab reduces and the bias
+// column sums: consumers of tensors that are final when the record is reached (x of the forward pass, dy), producers of
+// tensors nobody on the plan reads (dW is read by the optimizer / the gradient exchange) -- are enqueued on `side`; everything
+// else stays on `main`.  Between dependent kernels of ONE stream the chip drains and refills (the tail of a grouped convolution
+// launch runs a quarter of the CUs; an element-wise BatchNorm pass leaves the matrix pipes idle, a convolution the HBM): the side
+// stream's workgroups fill those holes.  Unlike round 1's eight streams this costs ONE event pair per run of side records:
+//   side record after main records:  record(ev_fork, main); wait(side, ev_fork)      -- dy is final
+//   end of the call:                 record(ev_join, side); wait(main, ev_join)      -- dW is final for whoever follows on main
+// A stream wait captures the event's state at the time of the call, so the two events can be re-recorded at every fork / join.
+// Streams and events belong to the caller (the library keeps no state); side == nullptr runs everything on `main`.
+extern "C" int bpb_plan_run2(const BpbPlanOp* ops, int nops, hipStream_t main, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join)
+{
+    if (side == nullptr) return bpb_plan_run(ops, nops, main);
+    BPB_REQUIRE(ev_fork != nullptr && ev_join != nullptr, "bpb_plan_run2: a side stream needs the fork and join events");
+    bool main_ahead = true, side_used = false;
+    for (int k = 0; k < nops; ++k) {
+        const BpbPlanOp& o = ops[k];
+        if (o.kind == BPB_OP_FORK || o.kind == BPB_OP_JOIN || o.kind == BPB_OP_DEP) continue;
+        int rc;
+        if (o.i[10] == 1) {
+            if (main_ahead) {
+                hipError_t e = hipEventRecord(ev_fork, main);
+                if (e == hipSuccess) e = hipStreamWaitEvent(side, ev_fork, 0);
+                if (e != hipSuccess) return bpb_set_error((int)e, "bpb_plan_run2: fork: %s", hipGetErrorString(e));
+                main_ahead = false;
+            }
+            side_used = true;
+            rc = run_one(o, k, side);
+        } else {
+            main_ahead = true;
+            rc = run_one(o, k, main);
+        }
+        if (rc != 0) return rc;
+    }
+    if (side_used) {
+        hipError_t e = hipEventRecord(ev_join, side);
+        if (e == hipSuccess) e = hipStreamWaitEvent(main, ev_join, 0);
+        if (e != hipSuccess) return bpb_set_error((int)e, "bpb_plan_run2: join: %s", hipGetErrorString(e));
+    }
+    return 0;
+}
+
+// Events for bpb_plan_run2 (timing disabled: cheapest record / wait).  The caller owns the handle.
+extern "C" int bpb_event_create(hipEvent_t* out)
+{
+    BPB_REQUIRE(out != nullptr, "bpb_event_create: null result pointer");
+    const hipError_t e = hipEventCreateWithFlags(out, hipEventDisableTiming);
+    return e == hipSuccess ? 0 : bpb_set_error((int)e, "bpb_event_create: %s", hipGetErrorString(e));
+}
+
+extern "C" int bpb_event_destroy(hipEvent_t ev)
+{
+    const hipError_t e = ev ? hipEventDestroy(ev) : hipSuccess;
+    return e == hipSuccess ? 0 : bpb_set_error((int)e, "bpb_event_destroy: %s", hipGetErrorString(e));
+}
+
 // Measurement variant: brackets every record with HIP events ON THE SAME STREAM and returns the elapsed milliseconds per
 // launch in ms_out[nops] (synchronises at the end).  Each record is launched BPB_TIMED_REPS times back to back between its
 // two events and the time divided: the fixed event / launch gap (~3 us, as large as some of the kernels) is amortised, so

@@ -75,13 +75,14 @@ def choose_tile(n, a, b, pixels):
 class Rec:
     """One record of a plan before freezing: either a ready PlanOp (`op`) or a mergeable descriptor (`desc` + `key`)."""
 
-    __slots__ = ('kind', 'label', 'flops', 'bytes', 'desc', 'key', 'op', 'blocks', 'work', 'mode', 'slot', 'together')
+    __slots__ = ('kind', 'label', 'flops', 'bytes', 'desc', 'key', 'op', 'blocks', 'work', 'mode', 'slot', 'together', 'side')
 
     def __init__(self, kind, label, flops=0.0, bytes_=0.0, desc=None, key=None, op=None, blocks=0, work=0.0, mode=0, together=None):
         self.kind, self.label, self.flops, self.bytes = kind, label, float(flops), float(bytes_)
         self.desc, self.key, self.op, self.blocks, self.work, self.mode = desc, key, op, int(blocks), float(work), int(mode)
         self.slot = 0
         self.together = together     # consecutive records of one chain with the same tag are independent: one launch
+        self.side = False            # True: nothing on the plan reads what this record writes (weight gradients) -> side stream
 
 
 class PlanList(list):
@@ -183,6 +184,9 @@ class Net:
         self.dgrad_bn_partials = os.environ.get('BPB_DGRAD_BN', '1') != '0'    # BatchNorm-backward partials from the dgrad epilogue
         self.eval_residual_epilogue = os.environ.get('BPB_EVAL_RES', '1') != '0'   # eval plan: residual adds in the conv epilogue
         self.bn_momentum = BN_MOMENTUM     # running-statistics momentum of every BatchNorm of this plan
+        # weight-gradient launches (+ their slab reduces) of the backward plan on a second stream (csrc/plan.cpp: bpb_plan_run2)
+        self.side_stream = os.environ.get('BPB_SIDE_STREAM', '1') != '0'
+        self._side = None                  # (torch stream, fork event, join event), created on first use
 
     # ------------------------------------------------------------------ graph construction
     def _node(self, kind, payload):
@@ -881,9 +885,11 @@ class Net:
         arr = (PlanOp * max(1, len(groups)))()
         meta = []
         for k, g in enumerate(groups):
+            side = 1 if (self.side_stream and all(r_.side for r_ in g)) else 0
             if g[0].op is not None:
                 assert len(g) == 1
                 arr[k] = g[0].op
+                arr[k].i[10] = side
                 meta.append({'label': g[0].label, 'flops': g[0].flops, 'bytes': g[0].bytes, 'n': 1})
                 continue
             g = sorted(g, key=lambda r_: -r_.work)          # stable: heaviest workgroups first in the grid
@@ -901,6 +907,7 @@ class Net:
                 blk += r_.blocks
             dev = self._dev_struct(host)
             arr[k] = self._op(g[0].kind, ints=(len(g), blk, g[0].mode), ptrs=(dev, C.addressof(host)))
+            arr[k].i[10] = side
             label = g[0].label if len(g) == 1 else '%s x%d' % (g[0].label, len(g))
             meta.append({'label': label, 'flops': sum(r_.flops for r_ in g), 'bytes': sum(r_.bytes for r_ in g), 'n': len(g)})
         self.keep.append(arr)
@@ -1246,6 +1253,7 @@ class Net:
             wp.nsplit = w1.nsplit                              # (the slab reduce record below reads the split count from wp)
             elems = w1.nsplit * x.C * cout
             self.debug_wgrad1x1.append((w1, cv))
+        n_before = len(bwd)
         if w1 is not None:
             bwd.add(Rec(nv.OP_WGRAD1X1, 'conv_wgrad bpb_wgrad1x1_kernel<%d>' % w1.lwm, 2.0 * y.N * y.H * y.W * x.C * cout,
                         4.0 * (x.buf.numel() + y.buf.numel()), desc=w1, key=('wg1',), blocks=w1.nsplit * w1.n_citiles * w1.n_cotiles,
@@ -1258,12 +1266,15 @@ class Net:
             kname = 'bpb_conv_wgrad_kernel<%d,%d>' % (1 if t == 1 else 9, ntw)
             bwd.add(Rec(nv.OP_WGRAD, 'conv_wgrad ' + kname, 2.0 * y.N * y.H * y.W * t * x.C * cout, 4.0 * (x.buf.numel() + y.buf.numel()),
                         desc=wp, key=('wg', t == 1, ntw), blocks=wp.nsplit * pairs, work=float(_cdiv(wp.n_mtiles, wp.nsplit) * min(t, 9) * ntw)))
+        for r_ in bwd[n_before:]:
+            r_.side = True       # reads x (forward pass) and dy (final here), writes its own slab range: independent of the chain
         rd = WgradReduceDesc()
         rd.dw = cv.weight.grad.data_ptr()
         rd.nsplit, rd.T, rd.Cin, rd.Cin_real, rd.Cout, rd.accumulate = wp.nsplit, t, x.C, cin_real, cout, 0
         rd.pad_ = 0 if wp.nsplit <= 4 else 2 if wp.nsplit <= 32 else 4      # split lanes per block (see bpb_wgrad_reduce_body)
         rec_r = Rec(nv.OP_WGRAD_REDUCE_MULTI, 'wgrad_reduce', 0, 4.0 * (elems + t * cin_real * cout), desc=rd, key=('wgr',),
                     blocks=_cdiv(t * x.C * cout, 256 >> rd.pad_))
+        rec_r.side = True
         # the slab reduce only has to run before the optimizer / the gradient exchange reads dW: the reduces of a whole fork
         # region are launched together at its end (<= 16 convolutions per launch) instead of one small launch per conv level
         self._pending_reduce.append(rec_r)
@@ -1274,6 +1285,7 @@ class Net:
             # BeforePoolingDimReduceLayer bpbreid.py:283-293); under a following BatchNorm it is round-off around zero
             rec_b = self._single(nv.OP_COLSUM, 'conv_bias_grad', 0, 4.0 * y.buf.numel(), ints=(y.N * y.H * y.W, cout, 0),
                                  ptrs=(gy, cv.bias.grad))
+            rec_b.side = True
             bwd.add(rec_b)
             self.grad_writers.append((rec_b, [cv.bias.grad]))
         # ---- data gradient
@@ -1319,7 +1331,34 @@ class Net:
         arr, n = plan[0], plan[1]
         end = n if end is None else end
         if end > begin:
-            nv.call('bpb_plan_run', C.c_void_p(C.addressof(arr) + begin * C.sizeof(PlanOp)), end - begin, nv.stream())
+            ops = C.c_void_p(C.addressof(arr) + begin * C.sizeof(PlanOp))
+            if self.side_stream and plan is getattr(self, 'plan_bwd', None):
+                side, ev_fork, ev_join = self._side_objects()
+                nv.call('bpb_plan_run2', ops, end - begin, nv.stream(), C.c_void_p(side.cuda_stream), ev_fork, ev_join)
+            else:
+                nv.call('bpb_plan_run', ops, end - begin, nv.stream())
+
+    def _side_objects(self):
+        if self._side is None:
+            prio = int(os.environ.get('BPB_SIDE_PRIO', '0'))
+            with torch.cuda.device(self.device):
+                side = torch.cuda.Stream(device=self.device, priority=prio)
+            evs = []
+            for _ in range(2):
+                h = C.c_void_p()
+                nv.call('bpb_event_create', C.byref(h))
+                evs.append(h)
+            self._side = (side, evs[0], evs[1])
+        return self._side
+
+    def __del__(self):
+        if getattr(self, '_side', None) is not None:
+            for ev in self._side[1:]:
+                try:
+                    nv.lib().bpb_event_destroy(ev)
+                except Exception:
+                    pass
+            self._side = None
 
     def grad_ready_positions(self):
         """[(launch index in plan_bwd, gradient tensor)]: after that launch the tensor (a view into the gradient arena) holds

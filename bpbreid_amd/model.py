@@ -256,6 +256,7 @@ class BPBreID(nn.Module):
         # (the reference only feeds it to its feature-map visualisation, part_based_engine.py:82-84).
         self.materialize_spatial_features = True
         self._eval_weights_frozen = False
+        self._eval_side = None
 
     def eval_weights_cached(self):
         """Context manager for a run of eval-mode forwards between which no parameter or BatchNorm buffer changes (feature
@@ -333,14 +334,41 @@ class BPBreID(nn.Module):
                 p.grad = v
 
     # ---------------------------------------------------------------- plans
-    def _plan(self, n, h, w, device):
-        key = (n, h, w)
+    def _plan(self, n, h, w, device, replica=0):
+        key = (n, h, w) if replica == 0 else (n, h, w, replica)
         st = self._plans.get(key)
         if st is None:
             self.rebind_grads()
             st = _ModelPlan(self, n, h, w, device)
             self._plans[key] = st
         return st
+
+    def _forward_eval_halves(self, images, masks):
+        """Eval-mode forward of an even batch as two half batches on two streams (BPB_EVAL_SPLIT, default on from 16 images).
+        In eval mode every image is independent of the rest of its batch (BatchNorm runs on the running statistics), and the
+        plan of one batch is a CHAIN of dependent launches: between two of them the chip drains and refills (the tail of a grouped
+        convolution launch keeps a quarter of the CUs busy).  Two independent chains fill each other's tails.  Results are
+        bit-identical to the one-batch forward (same kernels, same summation order per output element)."""
+        n, _, h, w = images.shape
+        hb = n // 2
+        main = torch.cuda.current_stream()
+        if self._eval_side is None:
+            self._eval_side = torch.cuda.Stream(device=images.device)
+        side = self._eval_side
+        side.wait_stream(main)
+        halves = []
+        for r, stream in ((0, main), (1, side)):
+            plan = self._plan(hb, h, w, images.device, replica=r)
+            with torch.cuda.stream(stream):
+                im = images[r * hb:(r + 1) * hb]
+                mk = masks[r * hb:(r + 1) * hb] if masks is not None else None
+                halves.append(plan.pack_outputs(_ModelFn.apply(self._anchor, im, self, plan, mk)))
+        main.wait_stream(side)
+        cat = lambda a, b: None if a is None else torch.cat((a, b), 0)
+        out = []
+        for a, b in zip(*halves):
+            out.append({k: cat(a[k], b[k]) for k in a} if isinstance(a, dict) else cat(a, b))
+        return tuple(out)
 
     def forward(self, images, external_parts_masks=None):
         if images.device.type != 'cuda':
@@ -351,8 +379,12 @@ class BPBreID(nn.Module):
             # the reference's BatchNorm1d layers (bpbreid.py:335, :405) refuse a single sample in training mode
             raise ValueError('Expected more than 1 value per channel when training, got input size torch.Size([1, %d])'
                              % self.dim_reduce_output)
-        plan = self._plan(n, h, w, images.device)
         needs_masks = (not self.learnable_attention_enabled) or (not self.training and self.test_use_target_segmentation != 'none')
+        split_from = int(os.environ.get('BPB_EVAL_SPLIT', '16'))
+        if (not self.training and split_from > 0 and n >= split_from and n % 2 == 0 and not torch.is_grad_enabled()
+                and not self.materialize_spatial_features and not torch.cuda.is_current_stream_capturing()):
+            return self._forward_eval_halves(images, external_parts_masks if needs_masks else None)
+        plan = self._plan(n, h, w, images.device)
         outs = _ModelFn.apply(self._anchor, images, self, plan, external_parts_masks if needs_masks else None)
         return plan.pack_outputs(outs)
 

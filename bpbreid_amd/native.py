@@ -241,7 +241,7 @@ PROTOS = {
     'bpb_bn1d_fwd': 'plpliippppppffiip', 'bpb_bn1d_bwd': 'plplplpliipppppiip',
     'bpb_ce_label_smooth': 'plpipiiifppplpp', 'bpb_pixel_ce': 'pppiiiiiifppipp',
     'bpb_part_triplet': 'pllppipiiiiffppppppp', 'bpb_ce_weight_grad': 'pppipp', 'bpb_part_triplet_bwd': 'pllppfiiipllip',
-    'bpb_scale': 'ppfplip', 'bpb_adam_step': 'ppppppifffffifppp', 'bpb_fill': 'pflp', 'bpb_plan_run': 'pip', 'bpb_plan_run_timed': 'pipp',
+    'bpb_scale': 'ppfplip', 'bpb_adam_step': 'ppppppifffffifppp', 'bpb_fill': 'pflp', 'bpb_plan_run': 'pip', 'bpb_plan_run2': 'pipppp', 'bpb_event_create': 'p', 'bpb_event_destroy': 'p', 'bpb_plan_run_timed': 'pipp',
     'bpb_part_distance': 'ppppiiiiiiipppppip', 'bpb_part_distance_fill': 'plpp', 'bpb_l2_normalize_rows': 'pplifp',
     'bpb_mask_preprocess': 'pppiiiiiiiiiffpp', 'bpb_bn_eval_affine_batched': 'piifp',
     'bpb_eval_rank': 'pppppiiiipppp', 'bpb_re_ranking': 'pppiiiifip', 'bpb_re_ranking_gpu_workspace': 'iiiipp',
@@ -259,7 +259,7 @@ EXPORTS = [
     'bpb_softmax_masks', 'bpb_visibility', 'bpb_pool_finalize', 'bpb_rowdot', 'bpb_head_bwd_dlogits',
     'bpb_head_bwd_params', 'bpb_head_bwd_dx', 'bpb_gemm', 'bpb_gemm_grouped', 'bpb_colsum', 'bpb_bn1d_fwd', 'bpb_bn1d_bwd',
     'bpb_ce_label_smooth', 'bpb_ce_weight_grad', 'bpb_pixel_ce', 'bpb_part_triplet', 'bpb_part_triplet_bwd', 'bpb_scale', 'bpb_adam_step',
-    'bpb_fill', 'bpb_plan_run', 'bpb_plan_run_timed', 'bpb_part_distance', 'bpb_part_distance_fill', 'bpb_l2_normalize_rows', 'bpb_eval_rank',
+    'bpb_fill', 'bpb_plan_run', 'bpb_plan_run2', 'bpb_event_create', 'bpb_event_destroy', 'bpb_plan_run_timed', 'bpb_part_distance', 'bpb_part_distance_fill', 'bpb_l2_normalize_rows', 'bpb_eval_rank',
     'bpb_mask_preprocess', 'bpb_re_ranking', 'bpb_re_ranking_gpu', 'bpb_re_ranking_gpu_workspace', 'bpb_eval_rank_gpu', 'bpb_bn_eval_affine_batched', 'bpb_resize_masks', 'bpb_attention_from_masks', 'bpb_pixel_dots_multi', 'bpb_masked_pool_multi', 'bpb_pool_finalize_multi', 'bpb_argsort_rows_gpu_workspace', 'bpb_argsort_rows_gpu', 'bpb_conv_s1_init', 'bpb_conv_s1', 'bpb_wgrad16_init', 'bpb_conv_wgrad16', 'bpb_wgrad1x1_init', 'bpb_conv_wgrad1x1', 'bpb_fuse_fwd_multi', 'bpb_term_bwd_multi', 'bpb_bn_finalize_multi',
     'bpb_bn_bwd_finalize_multi', 'bpb_wgrad_reduce_multi',
     'bpb_weighted_sum', 'bpb_scalar_fanout', 'bpb_lowres_stats_rows', 'bpb_lowres_stats', 'bpb_lowres_upsample_sum', 'bpb_lowres_adjoint', 'bpb_lowres_dx',

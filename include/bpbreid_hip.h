@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #else
 typedef struct ihipStream_t* hipStream_t;
+typedef struct ihipEvent_t* hipEvent_t;
 #endif
 
 #ifdef __cplusplus
@@ -593,6 +594,13 @@ int bpb_mask_preprocess(const float* raw, const int* group_offsets, const int* g
 
 /* ---- launch-plan executor: the static op list of one forward / backward (hrnet.py:532-576, resnet.py:342-358) ------ */
 int bpb_plan_run(const BpbPlanOp* ops, int nops, hipStream_t stream);
+/* the same walk over two streams: records with i[10] == 1 (weight gradients, slab reduces, bias sums: nothing on the plan reads
+ * their results) go to `side`, forked from / joined into `main` with the caller's two events; side == NULL = bpb_plan_run.
+ * Replaces what autograd's engine does for hrnet.py:532-576 backward (independent weight / data gradients of one layer). */
+int bpb_plan_run2(const BpbPlanOp* ops, int nops, hipStream_t main, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join);
+/* events for bpb_plan_run2 (timing disabled); owned by the caller */
+int bpb_event_create(hipEvent_t* out);
+int bpb_event_destroy(hipEvent_t ev);
 /* measurement only: per-op elapsed milliseconds via HIP events on `stream` (synchronises) */
 int bpb_plan_run_timed(const BpbPlanOp* ops, int nops, hipStream_t stream, float* ms_out);
 

@@ -1,0 +1,125 @@
+"""GPU tests of the two-stream schedules (round 4): they re-order WHEN kernels run, never what they compute, so every result must be
+bit-identical to the one-stream schedule.
+  * backward plan: weight-gradient launches + slab reduces on a side stream (csrc/plan.cpp: bpb_plan_run2, graph.Net.run)
+  * eval forward: an even batch as two half-batch plans on two streams (model.BPBreID._forward_eval_halves)
+Reference semantics: autograd's engine is free to run the weight and data gradient of a layer in any order
+(torchreid/models/hrnet.py:532-576 backward); eval-mode rows are independent of their batch (bpbreid.py:116-259 with BatchNorm on
+the running statistics)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import common as Cm                                            # noqa: E402
+from bpbreid_amd.model import bpbreid                         # noqa: E402
+from bpbreid_amd.engine import ImagePartBasedEngine           # noqa: E402
+from bpbreid_amd.optim import FusedAdam                       # noqa: E402
+
+DEV = torch.device('cuda', 0)
+WEIGHTS = {'globl': {'id': 1., 'tr': 0.}, 'foreg': {'id': 1., 'tr': 1.}, 'conct': {'id': 1., 'tr': 0.},
+           'parts': {'id': 0., 'tr': 1.}, 'pixls': {'ce': 0.35}}
+
+
+class _Env:
+    def __init__(self, **env):
+        self.env = env
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.env}
+        os.environ.update(self.env)
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize('backbone', ['hrnet_w16', 'resnet50'])
+def test_side_stream_backward_is_bit_identical_to_the_one_stream_plan(backbone):
+    k, d, n, h, w, ncls = 3, 64, 8, 128, 64, 16
+    cfg = Cm.make_cfg(backbone, k, d)
+    imgs, masks, pids = Cm.synth_batch(n, h, w, k, ncls)
+    data = {'image': imgs.to(DEV), 'mask': masks.to(DEV), 'pid': pids.to(DEV)}
+
+    def run(side):
+        with _Env(BPB_SIDE_STREAM=side):
+            model = Cm.fill_state_dict_(bpbreid(ncls, config=cfg, pretrained=False)).to(DEV)
+            eng = ImagePartBasedEngine(model, optimizer=FusedAdam(model, lr=1e-3), losses_weights=WEIGHTS, mask_filtering_training=True)
+            grads, losses = [], []
+            for _ in range(3):
+                loss, _ = eng.forward_backward(data)
+                grads.append(model.arena()['grad'].clone())
+                losses.append(float(loss))
+            torch.cuda.synchronize()
+            net = next(iter(model._plans.values())).net
+            nside = sum(int(net.plan_bwd[0][q].i[10]) for q in range(net.plan_bwd[1]))
+            return grads, losses, model.arena()['param'].clone(), nside
+
+    g0, l0, p0, ns0 = run('0')
+    g1, l1, p1, ns1 = run('1')
+    assert ns0 == 0 and ns1 > 0, 'the side-stream plan must carry weight-gradient records'
+    assert l0 == l1
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
+    assert torch.equal(p0, p1)
+
+
+def test_side_stream_backward_under_hipgraph_capture():
+    """The fork / join events of the two-stream backward become graph edges: a captured step replays bit-identically."""
+    k, d, n, h, w, ncls = 3, 64, 8, 64, 32, 16
+    cfg = Cm.make_cfg('hrnet_w8', k, d)
+    imgs, masks, pids = Cm.synth_batch(n, h, w, k, ncls)
+    data = {'image': imgs.to(DEV), 'mask': masks.to(DEV), 'pid': pids.to(DEV)}
+
+    def run(graph):
+        with _Env(BPB_SIDE_STREAM='1'):
+            model = Cm.fill_state_dict_(bpbreid(ncls, config=cfg, pretrained=False)).to(DEV)
+            eng = ImagePartBasedEngine(model, optimizer=FusedAdam(model, lr=1e-3), losses_weights=WEIGHTS, mask_filtering_training=True)
+            step = eng.capture_step(data, warmup=2) if graph else (lambda: eng.forward_backward(data))
+            out = []
+            for _ in range(3):
+                loss, _ = step()
+                out.append(float(loss))
+            torch.cuda.synchronize()
+            return out, model.arena()['param'].clone()
+
+    l0, p0 = run(False)
+    l1, p1 = run(True)
+    assert l0 == l1 and torch.equal(p0, p1)
+
+
+@pytest.mark.parametrize('backbone', ['hrnet_w16', 'resnet50'])
+def test_eval_forward_as_two_half_batches_is_bit_identical(backbone):
+    k, d, n, h, w, ncls = 5, 64, 16, 128, 64, 16
+    cfg = Cm.make_cfg(backbone, k, d)
+    imgs, masks, _ = Cm.synth_batch(n, h, w, k, ncls)
+    imgs, masks = imgs.to(DEV), masks.to(DEV)
+    model = Cm.fill_state_dict_(bpbreid(ncls, config=cfg, pretrained=False)).to(DEV)
+    model.materialize_spatial_features = False
+    model.eval()
+
+    def fwd(split):
+        with _Env(BPB_EVAL_SPLIT=split), torch.no_grad():
+            out = model(imgs, external_parts_masks=masks)
+            torch.cuda.synchronize()
+            return out
+
+    one = fwd('0')
+    assert (n, h, w) in model._plans and (n // 2, h, w, 1) not in model._plans
+    two = fwd('16')
+    assert (n // 2, h, w) in model._plans and (n // 2, h, w, 1) in model._plans
+    again = fwd('16')
+    for a, b, c in zip(one, two, again):
+        if isinstance(a, dict):
+            assert a.keys() == b.keys()
+            for key in a:
+                assert a[key].shape == b[key].shape and a[key].dtype == b[key].dtype, key
+                assert torch.equal(a[key], b[key]) and torch.equal(a[key], c[key]), key
+        elif a is None:
+            assert b is None
+        else:
+            assert torch.equal(a, b) and torch.equal(a, c)
