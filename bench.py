@@ -1,12 +1,15 @@
 """Headline benchmark: images/sec of the BPBReID train step (HRNet-W32, K=5 parts, 256x128, batch 64 per GPU).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: re-executes itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A step = one pass of the hot path over one synthetic batch already resident in HBM: backbone forward, part-attention
 pooling head, GiLt (identity CE + part triplet) + pixel CE, backward, gradient all-reduce (N > 1, RCCL), fused Adam.
-Rank 0 prints ONE JSON line; `roofline` is measured live with HIP events on the launch stream (bpb_plan_run_timed),
-`cpu_baseline` times the CPU oracle (a port of the reference's algorithm) on this box's host cores.
+Rank 0 prints ONE JSON line; `roofline` is measured live with HIP events on the launch stream (bpb_plan_run_timed) and carries
+`forward_only` (eval- and train-mode forward of the same batch: the north star's "fraction of the MFMA peak on the HRNet-W32
+forward"); `eval` is the config-5 evaluation path (part distance, ranking, argsort at Q=2048, G=20 000); `cpu_baseline` times the
+CPU oracle (a port of the reference's algorithm) on this box's host cores: the same train step, BASELINE config 1, and the
+distance + ranking of a query slice.
 """
 import argparse
 import json
@@ -40,7 +43,10 @@ def parse():
     ap.add_argument('--classes', type=int, default=751)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--cpu-batch', type=int, default=16)
+    ap.add_argument('--cpu-batch', type=int, default=0, help='batch of the CPU train-step leg (0: the GPU batch, falling back to 16 '
+                    'when that does not finish inside its time budget)')
+    ap.add_argument('--no-forward-only', action='store_true')
+    ap.add_argument('--no-eval', action='store_true')
     ap.add_argument('--graph', type=int, default=0,
                     help='1: replay the step from one hipGraph (same kernel time, ~1 ms instead of 20-28 ms of host work per step; '
                          'with --gpus N the RCCL all-reduce launches are captured with the step)')
@@ -49,7 +55,8 @@ def parse():
     ap.add_argument('--dump-plan-timing', default='', help='write the per-record isolated timings of the forward and backward '
                     'plans (label, kind, stream slot, ms) to this JSON file (input of tools/critical_path.py)')
     ap.add_argument('--same-data', action='store_true', help=argparse.SUPPRESS)     # tests: every rank gets rank 0's batch
-    ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-baseline-only', default='', help=argparse.SUPPRESS)        # child process: train | config1 | eval
+    ap.add_argument('--cpu-steps', default='3,5', help=argparse.SUPPRESS)             # warm-up,timed steps of the CPU train leg
     # functional check of the RCCL path on a one-GPU box: a world of ONE rank still goes through init_process_group('nccl'),
     # the parameter broadcast, the bucketed all-reduce overlapped with the backward plan and the exchange diagnostics
     ap.add_argument('--force-dist', action='store_true', help=argparse.SUPPRESS)
@@ -69,12 +76,11 @@ def host_cores():
     return max(1, min(n, 64))
 
 
-def cpu_baseline_subprocess(args, timeout=240):
-    """Run the CPU baseline in a child with a hard timeout so that the benchmark always terminates."""
+def _cpu_child(args, leg, timeout, extra=()):
+    """One CPU-baseline leg in a child process (GPUs hidden, hard timeout: the benchmark always terminates)."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', '--backbone', args.backbone, '--parts', str(args.parts),
-           '--height', str(args.height), '--width', str(args.width), '--classes', str(args.classes), '--cpu-batch', str(args.cpu_batch),
-           '--batch', str(args.batch)]
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', leg, '--backbone', args.backbone, '--parts', str(args.parts),
+           '--height', str(args.height), '--width', str(args.width), '--classes', str(args.classes), '--batch', str(args.batch)] + list(extra)
     env = dict(os.environ)
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
@@ -85,28 +91,57 @@ def cpu_baseline_subprocess(args, timeout=240):
         for line in r.stdout.decode().splitlines()[::-1]:
             if line.startswith('{'):
                 return json.loads(line)
-        return {'value': None, 'unit': 'images/sec', 'cores': host_cores(), 'kind': 'port', 'sample': 'cpu baseline produced no result'}
+        return {'value': None, 'unit': 'images/sec', 'cores': host_cores(), 'kind': 'port', 'sample': 'cpu baseline leg %s produced no result' % leg}
     except subprocess.TimeoutExpired:
         return {'value': None, 'unit': 'images/sec', 'cores': host_cores(), 'kind': 'port',
-                'sample': 'cpu baseline exceeded its %d s budget (batch %d)' % (timeout, args.cpu_batch)}
+                'sample': 'cpu baseline leg %s exceeded its %d s budget' % (leg, timeout)}
 
 
-def cpu_baseline(args):
+def cpu_baseline_subprocess(args):
+    """three legs of the CPU oracle on this box's host cores, each a bounded sample --
+      train_step   the bench workload itself (HRNet-W32 K=5 at the GPU batch; batch 16 if that does not fit the budget),
+      config1      ResNet-50 K=2, batch 16 (BASELINE configs[0], the reference's own CPU-runnable case),
+      eval         part-based distance + market1501 ranking of a 1024-query slice against the 20 000 gallery of config 5.
+    The top-level value / unit / cores / kind / sample are the train_step leg's (the metric of this bench line)."""
+    legs = {}
+    if args.cpu_batch:
+        legs['train_step'] = _cpu_child(args, 'train', 240, ['--cpu-batch', str(args.cpu_batch)])
+    else:
+        legs['train_step'] = _cpu_child(args, 'train', 150, ['--cpu-batch', str(args.batch), '--cpu-steps', '1,2'])
+        if legs['train_step'].get('value') is None:
+            note = legs['train_step'].get('sample')
+            legs['train_step'] = _cpu_child(args, 'train', 150, ['--cpu-batch', '16'])
+            legs['train_step']['sample'] = '%s [batch %d: %s]' % (legs['train_step'].get('sample'), args.batch, note)
+    legs['config1'] = _cpu_child(args, 'config1', 120)
+    legs['eval'] = _cpu_child(args, 'eval', 120)
+    out = dict(legs['train_step'])
+    out['legs'] = legs
+    return out
+
+
+def cpu_train_leg(backbone, parts, height, width, classes, n, warm, timed, gpu_batch):
     """The CPU oracle (a restatement of the reference's PyTorch path, materialised mask x feature product included)
-    timed on the host cores: bounded sample = batch `cpu_batch` (16: the reference's materialised [N,K,C,H,W] product needs
-    ~0.3 GB per image with autograd, a 64-batch would risk the box's memory), 3 warm-up + 5 timed steps (fwd + loss + bwd + Adam)."""
+    timed on the host cores: fwd + GiLt / pixel loss + bwd + Adam on a synthetic batch of `n`."""
     import common as Cm
     from oracle.bpbreid import BPBreID as OracleModel
     from oracle import losses as OL
     cores = host_cores()
     torch.set_num_threads(cores)
-    cfg = Cm.make_cfg(args.backbone, args.parts, 512)
-    model = Cm.fill_state_dict_(OracleModel(args.classes, cfg)).train()
+    if n > 16:
+        # the reference materialises the [N, K, C, H, W] mask x feature products with autograd (~0.3 GB per image on HRNet-W32):
+        # never drive the box out of memory for a baseline figure
+        try:
+            avail = [int(l.split()[1]) for l in open('/proc/meminfo') if l.startswith('MemAvailable')][0] / 2 ** 20
+        except Exception:
+            avail = 0.0
+        if avail < 0.75 * n + 8:
+            return {'value': None, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+                    'sample': 'batch %d needs ~%.0f GB of host memory, %.0f GB available' % (n, 0.75 * n + 8, avail)}
+    cfg = Cm.make_cfg(backbone, parts, 512)
+    model = Cm.fill_state_dict_(OracleModel(classes, cfg)).train()
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=3.5e-4, weight_decay=5e-4)
-    n = args.cpu_batch
-    imgs, masks, pids = Cm.synth_batch(n, args.height, args.width, args.parts, args.classes)
+    imgs, masks, pids = Cm.synth_batch(n, height, width, parts, classes)
     times = []
-    warm, timed = 3, 5
     for it in range(warm + timed):
         t0 = time.perf_counter()
         out = model(imgs, masks)
@@ -116,10 +151,60 @@ def cpu_baseline(args):
         opt.step()
         times.append(time.perf_counter() - t0)
     t = sum(times[warm:]) / timed
-    return {'value': n / t, 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+    return {'value': n / t, 'unit': 'images/sec', 'cores': torch.get_num_threads(), 'kind': 'port', 'ms_per_step': 1e3 * t, 'batch': n,
             'sample': '%s K=%d %dx%d, batch %d (GPU batch is %d), %d warm-up + %d timed train steps (%.1f s of CPU work), fp32, '
                       'oracle/ port of the reference PyTorch-CPU path'
-                      % (args.backbone, args.parts, args.height, args.width, n, args.batch, warm, timed, sum(times))}
+                      % (backbone, parts, height, width, n, gpu_batch, warm, timed, sum(times))}
+
+
+EVAL_SHAPE = (2048, 20000, 9, 512)          # BASELINE configs[4] / SURVEY.md 8d: queries, gallery, parts (incl. foreground), dim
+
+
+def eval_inputs(device=None):
+    """L2-normalised randn features, visibility Bernoulli(0.8) with column 0 forced true, pids uniform
+    over 1 500 identities, camids uniform over 6, seed 4321."""
+    import torch.nn.functional as F
+    Q, G, P, D = EVAL_SHAPE
+    g = torch.Generator().manual_seed(4321)
+    qf = F.normalize(torch.randn(Q, P, D, generator=g), dim=-1)
+    gf = F.normalize(torch.randn(G, P, D, generator=g), dim=-1)
+    qv = torch.rand(Q, P, generator=g) < 0.8
+    gv = torch.rand(G, P, generator=g) < 0.8
+    qv[:, 0], gv[:, 0] = True, True
+    ids = [torch.randint(0, hi, (m,), generator=g).numpy() for hi, m in ((1500, Q), (1500, G), (6, Q), (6, G))]
+    if device is not None:
+        qf, gf, qv, gv = (t.to(device) for t in (qf, gf, qv, gv))
+    return qf, gf, qv, gv, ids
+
+
+def cpu_eval_leg(nq=1024):
+    """compute_distance_matrix_using_bp_features (gallery chunks of 500 as the reference engine passes them,
+    torchreid/metrics/distance.py:87-247) + evaluate_rank (rank.py:97-159) of the CPU oracle on the first `nq` queries."""
+    from oracle import metrics as OM
+    torch.set_num_threads(host_cores())
+    qf, gf, qv, gv, (qp, gp, qc, gc) = eval_inputs()
+    Q, G, P, D = EVAL_SHAPE
+    t0 = time.perf_counter()
+    dm, _ = OM.part_based_distance(qf[:nq], gf, qv[:nq], gv, 'mean', 500, 'euclidean')
+    t_dist = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    OM.evaluate_rank(dm.numpy(), qp[:nq], gp, qc[:nq], gc, max_rank=50)
+    t_rank = time.perf_counter() - t0
+    return {'value': nq / (t_dist + t_rank), 'unit': 'queries/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'distance_ms': 1e3 * t_dist, 'rank_ms': 1e3 * t_rank, 'queries': nq, 'gallery': G,
+            'distance_ms_scaled_to_%d_queries' % Q: 1e3 * t_dist * Q / nq, 'rank_ms_scaled_to_%d_queries' % Q: 1e3 * t_rank * Q / nq,
+            'sample': 'first %d of the %d config-5 queries x %d gallery, P=%d D=%d, bool visibility, mean: %.1f s distance + %.1f s '
+                      'market1501 ranking, oracle/ port of distance.py + rank.py (both linear in the query count)' % (nq, Q, G, P, D, t_dist, t_rank)}
+
+
+def cpu_baseline(args):
+    leg = args.cpu_baseline_only
+    if leg == 'config1':
+        return cpu_train_leg('resnet50', 2, 256, 128, args.classes, 16, 3, 5, 16)
+    if leg == 'eval':
+        return cpu_eval_leg()
+    warm, timed = [int(v) for v in args.cpu_steps.split(',')]
+    return cpu_train_leg(args.backbone, args.parts, args.height, args.width, args.classes, args.cpu_batch or 16, warm, timed, args.batch)
 
 
 PMC_FILE = 'profiles/r03_pmc_hbm.json'
@@ -219,15 +304,99 @@ def roofline(model, plan):
     return r
 
 
+def spawn_argv(gpus, argv, port=None):
+    """`python bench.py --gpus N` started without a launcher (no WORLD_SIZE in the environment): the command line that runs the
+    same arguments as N ranks of one node, one process per GPU -- the form the driver itself uses for N > 1."""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(gpus), '--master-addr', '127.0.0.1',
+            '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def forward_only(model, data, dev):
+    """Eval- and train-mode forward of the bench batch alone (after the timed region): ms per batch and the fraction of the fp32
+    MFMA peak the backbone's convolution FLOPs (10.6 GFLOP per image on HRNet-W32 at 256x128) reach -- BASELINE.json north_star
+    ">= 60 % MFMA peak on HRNet-W32 forward".  Eval = what feature extraction runs (BatchNorm folded into the weights, parameter-
+    derived launches cached); train = the forward half of the train step (batch statistics)."""
+    out = {}
+    imgs, masks = data['image'], data['mask']
+    n = imgs.shape[0]
+    was_training = model.training
+    import contextlib
+    for mode in ('eval', 'train'):
+        model.train(mode == 'train')
+        cached = model.eval_weights_cached() if mode == 'eval' else contextlib.nullcontext()
+        with torch.no_grad(), cached:
+            for _ in range(3):
+                model(imgs, external_parts_masks=masks)
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 10
+            s.record()
+            for _ in range(reps):
+                model(imgs, external_parts_masks=masks)
+            e.record()
+            torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / reps
+        plan = [pl for pl in model._plans.values() if pl.N == n][0]
+        flops = sum(m['flops'] for m in (plan.net.plan_eval if mode == 'eval' else plan.net.plan_train)[2])
+        out[mode] = {'ms': ms, 'images_per_s': 1e3 * n / ms, 'conv_tflops': flops / ms * 1e-9, 'frac': flops / ms * 1e-9 / PEAK_F32_MFMA_TFLOPS}
+    model.train(was_training)
+    out['peak'] = PEAK_F32_MFMA_TFLOPS
+    out['unit'] = 'TFLOP/s'
+    return out
+
+
+def eval_block(dev):
+    """The evaluation path at BASELINE configs[4] size on this GPU (inputs resident in HBM): part-based distance with the per-part
+    matrix [P,Q,G] written (torchreid/metrics/distance.py:87-247) and without it, CMC / mAP (rank.py:97-159) and the ranked index
+    matrix (rank.py:110) of the distance matrix in HBM."""
+    from bpbreid_amd.metrics import compute_distance_matrix_using_bp_features, evaluate_rank
+    Q, G, P, D = EVAL_SHAPE
+    qf, gf, qv, gv, (qp, gp, qc, gc) = eval_inputs(dev)
+
+    def timed(fn, reps=5):
+        for _ in range(2):
+            r = fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            r = fn()
+        e.record()
+        torch.cuda.synchronize()
+        return r, s.elapsed_time(e) / reps
+    dist_fn = lambda parts: compute_distance_matrix_using_bp_features(qf, gf, qv, gv, 'mean', 500, True, 'euclidean',
+                                                                      return_device_tensors=True, want_parts=parts)
+    (dm, _), ms_parts = timed(lambda: dist_fn(True))
+    (dm, _), ms_plain = timed(lambda: dist_fn(False))
+    flops = 2.0 * P * Q * G * D
+    res, ms_rank = timed(lambda: evaluate_rank(dm, qp, gp, qc, gc, max_rank=50))
+    _, ms_sort = timed(lambda: evaluate_rank(dm, qp, gp, qc, gc, max_rank=50, return_indices=True))
+    return {'Q': Q, 'G': G, 'P': P, 'D': D, 'distance_ms': ms_parts, 'distance_tflops': flops / ms_parts * 1e-9,
+            'distance_frac': flops / ms_parts * 1e-9 / PEAK_F32_MFMA_TFLOPS, 'distance_ms_without_part_matrix': ms_plain,
+            'distance_frac_without_part_matrix': flops / ms_plain * 1e-9 / PEAK_F32_MFMA_TFLOPS, 'rank_ms': ms_rank,
+            'rank_plus_argsort_ms': ms_sort, 'argsort_ms': ms_sort - ms_rank, 'mAP': float(res['mAP']), 'rank1': float(res['cmc'][0])}
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args)))
         return
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # started plainly: become the launcher (one process per GPU over RCCL; rank 0 of the children prints the JSON line)
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        sys.stdout.flush()
+        argv = spawn_argv(args.gpus, sys.argv[1:])
+        os.execv(argv[0], argv)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    assert world == args.gpus, 'WORLD_SIZE=%d but --gpus %d: launch with torch.distributed.run --nproc-per-node %d' % (world, args.gpus, args.gpus)
     multi = world > 1 or args.force_dist
     if args.force_dist:
         os.environ['BPB_EXCHANGE_WORLD1'] = '1'
@@ -353,6 +522,14 @@ def main():
         step_flops = 3.0 * sum(m['flops'] for m in plan.net.plan_train[2])
         result['roofline']['step_conv_tflops'] = step_flops / (elapsed / args.steps) / 1e12
         result['roofline']['step_frac_of_f32_mfma_peak'] = result['roofline']['step_conv_tflops'] / PEAK_F32_MFMA_TFLOPS
+    if rank == 0 and not args.no_forward_only:
+        fo = forward_only(model, data, dev)
+        result.setdefault('roofline', {})['forward_only'] = fo
+    if rank == 0 and world == 1 and not args.no_eval:
+        try:
+            result['eval'] = eval_block(dev)
+        except Exception as ex:                          # a secondary figure: never lose the bench line over it
+            result['eval'] = {'error': repr(ex)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline_subprocess(args)
     if rank == 0:

@@ -300,7 +300,9 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob
                     }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_store(flags + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // flags[tile] counts the hand-overs PRODUCED for this tile, flags[ntiles + 1 + tile] the ones CONSUMED: a launch never
+            // resets anything, so a consumer that gave up (time-out below) cannot leave a stale "ready" behind for the next launch
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(flags + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef BPB_S1_TRACE
             S1_TR(4);
             if (g_s1_trace && (threadIdx.x & 63) == 0) {
@@ -312,14 +314,26 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob
 #endif
             return;
         }
+        // The wait is bounded (a lost hand-over must not hang the device).  Progress does NOT rest on the dispatch order: producers
+        // precede consumers in the grid and the dispatcher hands out blocks in index order (observed, not promised), so a consumer
+        // normally finds its producer resident; if it ever does not, the bounded wait ends, the tile is POISONED with NaN (the loss of
+        // the step turns NaN: loud), the time-out mark is set for Net.split_timeouts() and the hand-over still counts as consumed,
+        // so the late producer's increment pairs up with it and the NEXT launch waits for its own producer again.
+        int* s_timeout = (int*)((char*)smem + redbase);
         if (threadIdx.x == 0) {
-            int spins = 0;          // (bounded: a lost hand-over must not hang the device; the time-out mark is checked by the host tools)
-            while (__hip_atomic_load(flags + bid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(8);
-            if (spins >= (1 << 20)) __hip_atomic_store(flags + P.n_mtiles * P.n_ntiles, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(flags + bid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+            const int ntl = P.n_mtiles * P.n_ntiles;
+            const int want = __hip_atomic_load(flags + ntl + 1 + bid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+            int spins = 0;
+            while (__hip_atomic_load(flags + bid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want < 0 && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(8);
+            const int lost = spins >= (1 << 20);
+            if (lost) __hip_atomic_store(flags + ntl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(flags + ntl + 1 + bid, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *s_timeout = lost;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
+        const bool lost = *s_timeout != 0;
+        __syncthreads();                       // (the scratch word is the epilogue's: everyone has read it)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -331,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[mt][nt][q * 4 + e] += v[q][e];
+                    for (int e = 0; e < 4; ++e) acc[mt][nt][q * 4 + e] = lost ? __builtin_nanf("") : acc[mt][nt][q * 4 + e] + v[q][e];
             }
     }
     if (S1_ABL & 64) {

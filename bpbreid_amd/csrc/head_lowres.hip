@@ -355,8 +355,10 @@ static int lr_hwmax(const BpbHeadBranch* h_br, int nb)
 }
 static int lr_splits(const BpbHeadBranch* h_br, int nb, int px_per_block)
 {
-    int ps = bpb_cdiv(lr_hwmax(h_br, nb), px_per_block);
-    return ps < 1 ? 1 : (ps > 64 ? 64 : ps);
+    // (no upper clamp: lr_make_grid gives branch b cdiv(HW_b, px_per_block) splits, and every split owns a row of partials --
+    //  a 256 x 256 branch map has 128 of them)
+    const int ps = bpb_cdiv(lr_hwmax(h_br, nb), px_per_block);
+    return ps < 1 ? 1 : ps;
 }
 static LrGrid lr_make_grid(const BpbHeadBranch* h_br, int nb, int N, int px_per_block, int* nblocks)
 {
@@ -388,6 +390,8 @@ int bpb_lowres_stats(const BpbHeadBranch* d_br, const BpbHeadBranch* h_br, int n
     if (int rc = lr_check(h_br, nb, "bpb_lowres_stats")) return rc;
     int nblocks = 0;
     const LrGrid g = lr_make_grid(h_br, nb, N, LR_STATS_PX, &nblocks);
+    for (int b = 0; b < nb; ++b)
+        BPB_REQUIRE(g.psb[b] <= lr_splits(h_br, nb, LR_STATS_PX), "bpb_lowres_stats: branch %d has more pixel splits than partial rows", b);
     // (rows [psb, PS) of a branch with fewer splits are never written: the caller zero-fills `partials` once)
     hipLaunchKernelGGL(lr_stats_kernel, dim3(nblocks), dim3(256), 0, stream, d_br, g, nb, lr_splits(h_br, nb, LR_STATS_PX), Ct, partials);
     BPB_LAUNCH_OK();

@@ -70,6 +70,18 @@ class ImagePartBasedEngine:
         self.process_group = process_group
         self._reducer = None
         self.bucket_bytes = bucket_bytes
+        self._steps = 0
+        self.handover_check_every = 500      # train steps between two host checks of the K-split hand-over marks (one device sync)
+
+    def check_handovers(self):
+        """Raise if a K-split convolution workgroup ever gave up waiting for its partner (csrc/conv_s1.hip: bounded wait; the tile is
+        poisoned with NaN, so the step's loss is NaN as well).  One host synchronisation: called every `handover_check_every` train
+        steps, after the warm-up of capture_step and at the end of a feature extraction -- never per step."""
+        plans = getattr(self.model, '_plans', None) or {}
+        lost = sum(pl.net.split_timeouts() for pl in plans.values())
+        if lost:
+            raise nv.NativeError('bpbreid_amd: %d K-split hand-over(s) of the grouped convolution launches timed out; the affected '
+                                 'outputs are NaN.  Set BPB_S1_SPLIT_RATIO=0 to run without the K split.' % lost)
 
     # ------------------------------------------------------------------ training
     def parse_data_for_train(self, data):
@@ -111,6 +123,9 @@ class ImagePartBasedEngine:
             if scale != 1.0:
                 self.model.arena()['grad'].mul_(scale)
             self.optimizer.step()
+        self._steps += 1
+        if self.handover_check_every and self._steps % self.handover_check_every == 0 and not torch.cuda.is_current_stream_capturing():
+            self.check_handovers()
         return loss, loss_summary
 
     # ------------------------------------------------------------------ hipGraph replay of the whole step
@@ -152,6 +167,7 @@ class ImagePartBasedEngine:
                 self.forward_backward(static)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        self.check_handovers()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             loss, summary = self.forward_backward(static)
@@ -180,6 +196,9 @@ class ImagePartBasedEngine:
             if fused:
                 self.optimizer.step_index += 1       # mirrors step_dev, which the captured launch sequence increments
                 self.optimizer.updated |= captured
+            self._steps += 1
+            if self.handover_check_every and self._steps % self.handover_check_every == 0:
+                self.check_handovers()
             return loss, summary
 
         self._graph = graph
@@ -248,13 +267,21 @@ class ImagePartBasedEngine:
                 viss.append(v.clone())
                 pids.extend(int(x) for x in data.get('pid', []))
                 camids.extend(int(x) for x in data.get('camid', []))
-        f = torch.cat(feats) if feats else torch.empty(0, device=dev)
-        v = (torch.cat(viss) if viss else torch.empty(0, device=dev)) if self.mask_filtering_testing else None
+        self.check_handovers()
+        # (a rank whose share of the batches is empty still takes part in the all-gather below: rows of the right trailing shape)
+        nparts = sum(1 if e_ not in ('parts', 'bn_parts') else self.parts_num for e_ in self.test_embeddings)
+        width = getattr(self.model, 'dim_reduce_output', 0)
+        f = torch.cat(feats) if feats else torch.empty(0, nparts, width, device=dev)
+        v = (torch.cat(viss) if viss else torch.empty(0, nparts, device=dev, dtype=torch.bool if self._binary_test_visibility() else torch.float32)) \
+            if self.mask_filtering_testing else None
         if shard and gather and world > 1:
             f = all_gather_cat(f, 0, self.process_group)
             v = all_gather_cat(v.to(torch.float32), 0, self.process_group).to(v.dtype) if v is not None else None
             pids, camids = self._gather_labels(pids, dev), self._gather_labels(camids, dev)
         return f, v, pids, camids
+
+    def _binary_test_visibility(self):
+        return bool(getattr(self.model, 'testing_binary_visibility_score', True))
 
     def _gather_labels(self, labels, dev):
         from .distributed import all_gather_cat

@@ -931,7 +931,8 @@ class Net:
             if ratio <= 0 or len(g) < 2 or chain(r_) < ratio * lightest or (d.Cin // d.CK) % 2 or d.Cin // d.CK < 8:
                 continue
             part = torch.empty(ntiles * d.mt_r * d.nt * 4 * 256 * 4, device=self.device, dtype=torch.float32)
-            flags = torch.zeros(ntiles + 1, device=self.device, dtype=torch.int32)
+            # [0, ntiles): hand-overs produced per tile, [ntiles]: time-out mark, (ntiles, 2 * ntiles]: hand-overs consumed per tile
+            flags = torch.zeros(2 * ntiles + 1, device=self.device, dtype=torch.int32)
             sp = nv.S1Split()
             sp.part, sp.flags, sp.part_bytes = part.data_ptr(), flags.data_ptr(), part.numel() * 4
             d.split = self._dev_struct(sp).data_ptr()
@@ -1332,7 +1333,9 @@ class Net:
         end = n if end is None else end
         if end > begin:
             ops = C.c_void_p(C.addressof(arr) + begin * C.sizeof(PlanOp))
-            if self.side_stream and plan is getattr(self, 'plan_bwd', None):
+            # (not under hipGraph capture: the replay of a graph with the cross-stream edges measured SLOWER than the one-stream
+            #  graph, 33.7 vs 32.8 ms per step and 21 instead of 8 ms of host time per replay, gpurun_out/r04a)
+            if self.side_stream and plan is getattr(self, 'plan_bwd', None) and not torch.cuda.is_current_stream_capturing():
                 side, ev_fork, ev_join = self._side_objects()
                 nv.call('bpb_plan_run2', ops, end - begin, nv.stream(), C.c_void_p(side.cuda_stream), ev_fork, ev_join)
             else:

@@ -256,26 +256,37 @@ class BPBreID(nn.Module):
         # (the reference only feeds it to its feature-map visualisation, part_based_engine.py:82-84).
         self.materialize_spatial_features = True
         self._eval_weights_frozen = False
-        self._eval_side = None
 
     def eval_weights_cached(self):
         """Context manager for a run of eval-mode forwards between which no parameter or BatchNorm buffer changes (feature
         extraction over a query / gallery set): the parameter-derived launches of the eval plan -- the affine of every BatchNorm
         from its running statistics and the packing of the BN-folded convolution weights, 0.15-0.2 ms per forward -- run on the
-        first forward only.  Leaving the context (or a training forward / load_state_dict inside it) drops the cache."""
+        first forward only.  The cache is keyed by the model's PARAMETER VERSION (`bump_param_version`): every training forward
+        (BatchNorm running statistics), every optimizer step of bpbreid_amd.optim / the engine, load_state_dict and set_bn_momentum
+        advance it, and a plan whose derived weights belong to an older version re-derives them -- whichever plan (batch shape)
+        they ran on.  Code that edits parameters in place by other means inside the context calls bump_param_version() itself."""
         model = self
 
         class _Ctx:
             def __enter__(self_):
                 model._eval_weights_frozen = True
-                for pl in model._plans.values():
-                    pl.eval_weights_ready = False
+                model.bump_param_version()
                 return model
 
             def __exit__(self_, *exc):
                 model._eval_weights_frozen = False
                 return False
         return _Ctx()
+
+    def bump_param_version(self):
+        """Parameters or BatchNorm buffers changed: eval-plan launches derived from them (BatchNorm affines, BN-folded packed weights)
+        are stale for every plan."""
+        self._param_version = getattr(self, '_param_version', 0) + 1
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.bump_param_version()
+        return out
 
     # ---------------------------------------------------------------- flat arenas
     def flatten_parameters(self):
@@ -334,41 +345,14 @@ class BPBreID(nn.Module):
                 p.grad = v
 
     # ---------------------------------------------------------------- plans
-    def _plan(self, n, h, w, device, replica=0):
-        key = (n, h, w) if replica == 0 else (n, h, w, replica)
+    def _plan(self, n, h, w, device):
+        key = (n, h, w)
         st = self._plans.get(key)
         if st is None:
             self.rebind_grads()
             st = _ModelPlan(self, n, h, w, device)
             self._plans[key] = st
         return st
-
-    def _forward_eval_halves(self, images, masks):
-        """Eval-mode forward of an even batch as two half batches on two streams (BPB_EVAL_SPLIT, default on from 16 images).
-        In eval mode every image is independent of the rest of its batch (BatchNorm runs on the running statistics), and the
-        plan of one batch is a CHAIN of dependent launches: between two of them the chip drains and refills (the tail of a grouped
-        convolution launch keeps a quarter of the CUs busy).  Two independent chains fill each other's tails.  Results are
-        bit-identical to the one-batch forward (same kernels, same summation order per output element)."""
-        n, _, h, w = images.shape
-        hb = n // 2
-        main = torch.cuda.current_stream()
-        if self._eval_side is None:
-            self._eval_side = torch.cuda.Stream(device=images.device)
-        side = self._eval_side
-        side.wait_stream(main)
-        halves = []
-        for r, stream in ((0, main), (1, side)):
-            plan = self._plan(hb, h, w, images.device, replica=r)
-            with torch.cuda.stream(stream):
-                im = images[r * hb:(r + 1) * hb]
-                mk = masks[r * hb:(r + 1) * hb] if masks is not None else None
-                halves.append(plan.pack_outputs(_ModelFn.apply(self._anchor, im, self, plan, mk)))
-        main.wait_stream(side)
-        cat = lambda a, b: None if a is None else torch.cat((a, b), 0)
-        out = []
-        for a, b in zip(*halves):
-            out.append({k: cat(a[k], b[k]) for k in a} if isinstance(a, dict) else cat(a, b))
-        return tuple(out)
 
     def forward(self, images, external_parts_masks=None):
         if images.device.type != 'cuda':
@@ -380,10 +364,6 @@ class BPBreID(nn.Module):
             raise ValueError('Expected more than 1 value per channel when training, got input size torch.Size([1, %d])'
                              % self.dim_reduce_output)
         needs_masks = (not self.learnable_attention_enabled) or (not self.training and self.test_use_target_segmentation != 'none')
-        split_from = int(os.environ.get('BPB_EVAL_SPLIT', '16'))
-        if (not self.training and split_from > 0 and n >= split_from and n % 2 == 0 and not torch.is_grad_enabled()
-                and not self.materialize_spatial_features and not torch.cuda.is_current_stream_capturing()):
-            return self._forward_eval_halves(images, external_parts_masks if needs_masks else None)
         plan = self._plan(n, h, w, images.device)
         outs = _ModelFn.apply(self._anchor, images, self, plan, external_parts_masks if needs_masks else None)
         return plan.pack_outputs(outs)
@@ -392,6 +372,7 @@ class BPBreID(nn.Module):
         """Set the running-statistics momentum of every BatchNorm (the reference's modules carry it as `.momentum`,
         hrnet.py:13 BN_MOMENTUM = 0.1 and the nn.BatchNorm defaults).  The launch plans bake it in, so they are rebuilt."""
         self.bn_momentum = float(momentum)
+        self.bump_param_version()
         for mod in self.modules():
             if isinstance(mod, (nn.BatchNorm1d, nn.BatchNorm2d)):
                 mod.momentum = float(momentum)
@@ -638,7 +619,8 @@ class _ModelPlan:
         x = self.feats.buf
         fresh = None
         # head on the branch outputs, the concatenated map is never written (csrc/head_lowres.hip)?
-        low = (not m.materialize_spatial_features) and self._lowres_srcs is not None and os.environ.get('BPB_LOWRES_HEAD', '1') != '0'
+        # (its gradient kernel is instantiated for K + 1 <= 9 classes, csrc/head_lowres.hip: more parts take the materialised map)
+        low = (not m.materialize_spatial_features) and self._lowres_srcs is not None and self.K1 <= 9 and os.environ.get('BPB_LOWRES_HEAD', '1') != '0'
         if low and self.lr is None:
             self._init_lowres()
         self.low = low
@@ -646,12 +628,15 @@ class _ModelPlan:
         # eval plan: its leading launches (BatchNorm affines from the running statistics, packing of the BN-folded weights) depend
         # on the parameters only -- skipped while the model says they cannot have changed (BPBreID.eval_weights_cached)
         first = 0
+        version = getattr(m, '_param_version', 0)
         if training:
+            m.bump_param_version()               # running statistics move (and an optimizer step usually follows)
             self.eval_weights_ready = False
         elif m._eval_weights_frozen:
-            if getattr(self, 'eval_weights_ready', False):
+            if getattr(self, 'eval_weights_ready', False) and getattr(self, 'eval_weights_version', None) == version:
                 first = self.eval_param_launches()
             self.eval_weights_ready = True
+            self.eval_weights_version = version
         if low:
             net.run(net.plan_train if training else net.plan_eval, first, lr.cut['train' if training else 'eval'])
             if training:

@@ -77,6 +77,8 @@ class FusedAdam:
         nv.call('bpb_adam_step', a['param'].data_ptr(), a['grad'].data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                 offs.data_ptr(), lens.data_ptr(), nblocks, lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
                 self.step_index, grad_scale, self.step_dev.data_ptr(), self.lr_dev.data_ptr(), nv.stream())
+        if hasattr(self.model, 'bump_param_version'):
+            self.model.bump_param_version()        # eval-plan weights derived from the parameters are stale now
 
     def state_dict(self):
         """torch.optim.Adam's format ({'state': {i: {'step','exp_avg','exp_avg_sq'}}, 'param_groups': [...]}, positions =

@@ -508,7 +508,7 @@ def test_two_rank_data_parallel_matches_single_process(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     common = ['--steps', '3', '--warmup', '0', '--backbone', 'hrnet_w8', '--batch', '16', '--height', '128', '--width', '64',
-              '--classes', '32', '--no-cpu-baseline', '--no-roofline', '--same-data']
+              '--classes', '32', '--no-cpu-baseline', '--no-roofline', '--no-forward-only', '--no-eval', '--same-data']
     env = dict(os.environ)
     for kk in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(kk, None)
@@ -516,18 +516,16 @@ def test_two_rank_data_parallel_matches_single_process(tmp_path):
                          stderr=subprocess.PIPE, timeout=300, env=env)
     assert one.returncode == 0, one.stderr.decode()[-2000:]
     r1 = json.loads([l for l in one.stdout.decode().splitlines() if l.startswith('{')][-1])
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
-    two = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
-                          '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2',
-                          '--dist-backend', 'gloo'] + common, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
+    # started PLAINLY, exactly as the driver starts `--gpus 1`: bench.py re-executes itself under torch.distributed.run
+    two = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dist-backend', 'gloo'] + common,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
     err = two.stderr.decode()
     if two.returncode != 0 and ('gloo' in err.lower() and ('cuda' in err.lower() or 'hip' in err.lower()) and 'support' in err.lower()):
         pytest.skip('this torch build has no gloo support for device tensors')
     assert two.returncode == 0, err[-3000:]
-    r2 = json.loads([l for l in two.stdout.decode().splitlines() if l.startswith('{')][-1])
+    lines = [l for l in two.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, 'exactly ONE JSON line for the whole job: %r' % (lines,)
+    r2 = json.loads(lines[-1])
     assert r2['n_gpus'] == 2 and r2['config']['global_batch'] == 32 and r2['scaling'] == 'weak'
     gx = r2['config']['gradient_exchange']           # the self-verification block of the N > 1 bench line
     assert 'error' not in gx and gx['ranks'] == 2 and gx['buckets'] >= 1 and gx['buckets_started_under_backward'] >= gx['buckets'] - 1, gx

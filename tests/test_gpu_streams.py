@@ -1,10 +1,9 @@
-"""GPU tests of the two-stream schedules (round 4): they re-order WHEN kernels run, never what they compute, so every result must be
+"""GPU tests of the two-stream schedule (round 4): it re-orders WHEN kernels run, never what they compute, so every result must be
 bit-identical to the one-stream schedule.
   * backward plan: weight-gradient launches + slab reduces on a side stream (csrc/plan.cpp: bpb_plan_run2, graph.Net.run)
-  * eval forward: an even batch as two half-batch plans on two streams (model.BPBreID._forward_eval_halves)
 Reference semantics: autograd's engine is free to run the weight and data gradient of a layer in any order
-(torchreid/models/hrnet.py:532-576 backward); eval-mode rows are independent of their batch (bpbreid.py:116-259 with BatchNorm on
-the running statistics)."""
+(torchreid/models/hrnet.py:532-576 backward).  (An eval forward as two half-batch chains on two streams was measured too:
+7.76 -> 7.82 ms, both chains want the matrix pipes at the same time -- removed, gpurun_out/r04a.)"""
 import os
 
 import pytest
@@ -68,8 +67,9 @@ def test_side_stream_backward_is_bit_identical_to_the_one_stream_plan(backbone):
     assert torch.equal(p0, p1)
 
 
-def test_side_stream_backward_under_hipgraph_capture():
-    """The fork / join events of the two-stream backward become graph edges: a captured step replays bit-identically."""
+def test_captured_step_matches_the_eager_two_stream_step():
+    """Under hipGraph capture the backward plan stays on ONE stream (a graph with the fork / join edges replays slower: 33.7 vs
+    32.8 ms, 21 instead of 8 ms of host work per replay): the captured step must still equal the eager two-stream step bit for bit."""
     k, d, n, h, w, ncls = 3, 64, 8, 64, 32, 16
     cfg = Cm.make_cfg('hrnet_w8', k, d)
     imgs, masks, pids = Cm.synth_batch(n, h, w, k, ncls)
@@ -90,36 +90,3 @@ def test_side_stream_backward_under_hipgraph_capture():
     l0, p0 = run(False)
     l1, p1 = run(True)
     assert l0 == l1 and torch.equal(p0, p1)
-
-
-@pytest.mark.parametrize('backbone', ['hrnet_w16', 'resnet50'])
-def test_eval_forward_as_two_half_batches_is_bit_identical(backbone):
-    k, d, n, h, w, ncls = 5, 64, 16, 128, 64, 16
-    cfg = Cm.make_cfg(backbone, k, d)
-    imgs, masks, _ = Cm.synth_batch(n, h, w, k, ncls)
-    imgs, masks = imgs.to(DEV), masks.to(DEV)
-    model = Cm.fill_state_dict_(bpbreid(ncls, config=cfg, pretrained=False)).to(DEV)
-    model.materialize_spatial_features = False
-    model.eval()
-
-    def fwd(split):
-        with _Env(BPB_EVAL_SPLIT=split), torch.no_grad():
-            out = model(imgs, external_parts_masks=masks)
-            torch.cuda.synchronize()
-            return out
-
-    one = fwd('0')
-    assert (n, h, w) in model._plans and (n // 2, h, w, 1) not in model._plans
-    two = fwd('16')
-    assert (n // 2, h, w) in model._plans and (n // 2, h, w, 1) in model._plans
-    again = fwd('16')
-    for a, b, c in zip(one, two, again):
-        if isinstance(a, dict):
-            assert a.keys() == b.keys()
-            for key in a:
-                assert a[key].shape == b[key].shape and a[key].dtype == b[key].dtype, key
-                assert torch.equal(a[key], b[key]) and torch.equal(a[key], c[key]), key
-        elif a is None:
-            assert b is None
-        else:
-            assert torch.equal(a, b) and torch.equal(a, c)

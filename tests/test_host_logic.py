@@ -626,3 +626,36 @@ def test_roofline_traffic_is_quoted_only_from_a_profile_of_this_build(monkeypatc
     monkeypatch.setattr(build, 'source_id', lambda: 'ffffffffffffffff')
     stale = bench.pmc_traffic('void bpb_conv_s1_kernel<1, 1, 3, 1>(BpbConvS1Prob const*, BpbBlkBegins)')
     assert stale['traffic'] is None and 'not quoted' in stale['traffic_source']
+
+
+def test_bench_started_plainly_with_several_gpus_reexecutes_itself_under_the_launcher(monkeypatch):
+    """`python bench.py --gpus N` without WORLD_SIZE (how the driver starts `--gpus 1`) must become N ranks by itself: the re-exec
+    command line is torch.distributed.run with one process per GPU on 127.0.0.1 and the unchanged arguments; with WORLD_SIZE set
+    (a launcher is already there) nothing is re-executed and a rank-count mismatch is refused."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module('bench')
+    argv = bench.spawn_argv(8, ['--gpus', '8', '--steps', '20', '--warmup', '5'], port=29517)
+    assert argv[:3] == [sys.executable, '-m', 'torch.distributed.run']
+    assert argv[3:10] == ['--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1', '--master-port', '29517']
+    assert argv[10] == os.path.join(ROOT, 'bench.py') and argv[11:] == ['--gpus', '8', '--steps', '20', '--warmup', '5']
+    free = bench.spawn_argv(2, [])
+    assert 1024 < int(free[free.index('--master-port') + 1]) < 65536
+    # main(): no launcher -> exec of exactly that command; launcher present -> no exec
+    seen = {}
+
+    def fake_exec(path, args):
+        seen['argv'] = list(args)
+        raise SystemExit(0)
+    monkeypatch.setattr(os, 'execv', fake_exec)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '2'])
+    with pytest.raises(SystemExit):
+        bench.main()
+    assert seen['argv'][:3] == [sys.executable, '-m', 'torch.distributed.run'] and seen['argv'][5] == '4'
+    assert seen['argv'][-4:] == ['--gpus', '4', '--steps', '2']
+    seen.clear()
+    monkeypatch.setenv('WORLD_SIZE', '2')
+    with pytest.raises(AssertionError, match='WORLD_SIZE=2 but --gpus 4'):
+        bench.main()
+    assert not seen

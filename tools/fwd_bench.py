@@ -37,7 +37,7 @@ for mode in os.environ.get('BPB_FWD_MODES', 'eval,train').split(','):
         e.record()
         torch.cuda.synchronize()
     ms = s.elapsed_time(e) / reps
-    plan = next(iter(model._plans.values()))          # (eval may run as two half-batch plans: the FLOPs scale with the batch)
+    plan = next(iter(model._plans.values()))
     flops = sum(m['flops'] for m in (plan.net.plan_eval if mode == 'eval' else plan.net.plan_train)[2]) * n / plan.N
     res[mode] = {'ms_per_batch': ms, 'images_per_s': n / ms * 1e3, 'conv_tflops': flops / ms * 1e-9,
                  'frac_of_f32_mfma_peak': flops / ms * 1e-9 / 157.3}
