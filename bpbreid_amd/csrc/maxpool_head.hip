@@ -1,0 +1,167 @@
+// pooling = 'gmp': GlobalMaxPoolingHead of the part embeddings (torchreid/models/bpbreid.py:481-482 via :458-468 -- the
+// reference materialises mask x feature as [N*K, C, H, W] and runs nn.AdaptiveMaxPool2d((1, 1)) over it):
+//     pooled[n][3 + k][c] = max_p  m_k[n][p] * x[n][p][c]           (rows 0..2 -- global, foreground, background -- stay means)
+// with the arg-max pixel kept for the backward pass, which routes the gradient to that ONE pixel like AdaptiveMaxPool2d does
+// (first maximum in scan order on ties):
+//     d m_k[n][p*]    += G[n][3+k][c] * x[n][p*][c]                  (joins the softmax backward through D, bpb_head_bwd_dlogits)
+//     d x[n][p*][c]   += G[n][3+k][c] * m_k[n][p*]
+// Nothing of size [N, K, C, H, W] exists.  The maximum does not commute with the bilinear up-sampling of the HRNet branches, so this
+// head always reads the materialised map (model.py forces it).  No floating-point atomics: every sum has a fixed order.
+#include "bpb_common.h"
+
+#define MP_MAXK 9          // parts (the materialised head dispatches K + 1 <= 10 classes)
+#define MP_MAXC 4096       // channels of the map (LDS copy of the arg-max row in the mask-gradient kernel)
+
+// grid (ceil(C / 64), N); 256 threads = 4 pixel rows x 64 channels
+__global__ __launch_bounds__(256) void mp_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pm, float* __restrict__ pooled,
+                                                     int* __restrict__ arg, const float* __restrict__ zinv, float* __restrict__ zinv_dl,
+                                                     float* __restrict__ zinv_dx, int HW, int C, int J)
+{
+    __shared__ float sv[3][MP_MAXK][64];
+    __shared__ int sa[3][MP_MAXK][64];
+    const int n = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), row = threadIdx.x >> 6;
+    const int K = J - 3;
+    if (blockIdx.x == 0 && (int)threadIdx.x < J) {
+        // norms for the two backward kernels: the mask gradient of a part row is D itself (negative sign = "no normalisation term",
+        // bpb_head_bwd_dlogits), and the dense dx kernel must not add m * G for the part rows (coefficient |zinv| = 0)
+        const float z = zinv[(long)n * J + threadIdx.x];
+        zinv_dl[(long)n * J + threadIdx.x] = (int)threadIdx.x < 3 ? z : -1.f;
+        zinv_dx[(long)n * J + threadIdx.x] = (int)threadIdx.x < 3 ? z : 0.f;
+    }
+    float best[MP_MAXK];
+    int at[MP_MAXK];
+#pragma unroll
+    for (int k = 0; k < MP_MAXK; ++k) {
+        best[k] = -INFINITY;
+        at[k] = 0;
+    }
+    if (c < C) {
+        const float* xn = x + (long)n * HW * C + c;
+        const float* mn = pm + ((long)n * J + 3) * HW;
+        for (int p = row; p < HW; p += 4) {
+            const float xv = xn[(long)p * C];
+#pragma unroll
+            for (int k = 0; k < MP_MAXK; ++k)
+                if (k < K) {
+                    const float v = mn[(long)k * HW + p] * xv;
+                    if (v > best[k] || v != v) {          // (NaN propagates like ATen's adaptive_max_pool2d)
+                        best[k] = v;
+                        at[k] = p;
+                    }
+                }
+        }
+    }
+    if (row > 0) {
+#pragma unroll
+        for (int k = 0; k < MP_MAXK; ++k) {
+            sv[row - 1][k][threadIdx.x & 63] = best[k];
+            sa[row - 1][k][threadIdx.x & 63] = at[k];
+        }
+    }
+    __syncthreads();
+    if (row == 0 && c < C) {
+#pragma unroll
+        for (int k = 0; k < MP_MAXK; ++k)
+            if (k < K) {
+                float b = best[k];
+                int a = at[k];
+                for (int r = 0; r < 3; ++r) {
+                    const float v = sv[r][k][threadIdx.x & 63];
+                    const int q = sa[r][k][threadIdx.x & 63];
+                    const bool bn = b != b, vn = v != v;
+                    // first maximum in pixel order; a NaN wins over numbers, the earliest NaN over later ones
+                    if ((vn && (!bn || q < a)) || (!bn && !vn && (v > b || (v == b && q < a)))) {
+                        b = v;
+                        a = q;
+                    }
+                }
+                pooled[((long)n * J + 3 + k) * C + c] = b;
+                arg[((long)n * K + k) * C + c] = a;
+            }
+    }
+}
+
+// grid (K, N): D[n][p][2 + k] = sum over the channels whose arg-max pixel is p of G[n][3+k][c] * x[n][p][c], channels in ascending
+// order (fixed summation order).  D rows: [N*HW][K1 + 1] with columns fg, bg, part_1..K (bpb_head_bwd_dlogits).
+__global__ __launch_bounds__(256) void mp_bwd_dmask_kernel(const float* __restrict__ x, const float* __restrict__ G, const int* __restrict__ arg,
+                                                           float* __restrict__ D, int HW, int C, int J)
+{
+    __shared__ int s_at[MP_MAXC];
+    __shared__ float s_v[MP_MAXC];
+    const int k = blockIdx.x, n = blockIdx.y, K = J - 3, JD = J - 1;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int a = arg[((long)n * K + k) * C + c];
+        s_at[c] = a;
+        s_v[c] = G[((long)n * J + 3 + k) * C + c] * x[((long)n * HW + a) * C + c];
+    }
+    __syncthreads();
+    for (int p0 = 0; p0 < HW; p0 += 256 * 8) {
+        float s[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s[i] = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const int d = s_at[c] - p0 - (int)threadIdx.x;       // this thread owns pixels p0 + threadIdx.x + 256 * i
+            const float v = s_v[c];
+            if (d >= 0 && d < 256 * 8 && (d & 255) == 0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (d == 256 * i) s[i] += v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int p = p0 + (int)threadIdx.x + 256 * i;
+            if (p < HW) D[((long)n * HW + p) * JD + 2 + k] = s[i];
+        }
+    }
+}
+
+// grid (ceil(C / 256), N): dx[n][p*][c] += G[n][3+k][c] * m_k[n][p*], parts in ascending order inside ONE thread per (n, c) --
+// two parts of a channel may share their arg-max pixel, different channels never share an address.
+__global__ __launch_bounds__(256) void mp_bwd_dx_kernel(const float* __restrict__ G, const float* __restrict__ pm, const int* __restrict__ arg,
+                                                        float* __restrict__ dx, int HW, int C, int J)
+{
+    const int n = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x, K = J - 3;
+    if (c >= C) return;
+    for (int k = 0; k < K; ++k) {
+        const int a = arg[((long)n * K + k) * C + c];
+        const long at = ((long)n * HW + a) * C + c;
+        dx[at] += G[((long)n * J + 3 + k) * C + c] * pm[((long)n * J + 3 + k) * HW + a];
+    }
+}
+
+extern "C" {
+
+// Forward of the 'gmp' part rows on a materialised map x [N][HW][C] with the masks pm [N][J][HW] (rows 3.. = parts): overwrites
+// pooled[n][3..][:] (the mean rows 0..2 come from bpb_masked_pool / bpb_pool_finalize), writes the arg-max pixels arg [N][K][C] and
+// the two norm vectors the backward kernels take in place of zinv.
+int bpb_masked_maxpool_fwd(const float* x, const float* pm, float* pooled, int* arg, const float* zinv, float* zinv_dl, float* zinv_dx,
+                           int N, int HW, int C, int J, hipStream_t stream)
+{
+    BPB_REQUIRE(J >= 4 && J - 3 <= MP_MAXK, "bpb_masked_maxpool_fwd: %d parts (1..%d)", J - 3, MP_MAXK);
+    BPB_REQUIRE(N >= 1 && HW >= 1 && C >= 1, "bpb_masked_maxpool_fwd: empty problem");
+    hipLaunchKernelGGL(mp_fwd_kernel, dim3(bpb_cdiv(C, 64), N), dim3(256), 0, stream, x, pm, pooled, arg, zinv, zinv_dl, zinv_dx, HW, C, J);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+// Backward, mask side: overwrites the part columns of D (written by bpb_pixel_dots for the mean rows) with the arg-max form.
+int bpb_masked_maxpool_bwd_dmask(const float* x, const float* G, const int* arg, float* D, int N, int HW, int C, int J, hipStream_t stream)
+{
+    BPB_REQUIRE(J >= 4 && J - 3 <= MP_MAXK && C <= MP_MAXC, "bpb_masked_maxpool_bwd_dmask: %d parts, %d channels (<= %d, <= %d)", J - 3, C,
+                MP_MAXK, MP_MAXC);
+    hipLaunchKernelGGL(mp_bwd_dmask_kernel, dim3(J - 3, N), dim3(256), 0, stream, x, G, arg, D, HW, C, J);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+// Backward, feature side: adds the part rows' gradient at their arg-max pixels to dx (after bpb_head_bwd_dx ran with zinv_dx).
+int bpb_masked_maxpool_bwd_dx(const float* G, const float* pm, const int* arg, float* dx, int N, int HW, int C, int J, hipStream_t stream)
+{
+    BPB_REQUIRE(J >= 4 && J - 3 <= MP_MAXK, "bpb_masked_maxpool_bwd_dx: %d parts (1..%d)", J - 3, MP_MAXK);
+    hipLaunchKernelGGL(mp_bwd_dx_kernel, dim3(bpb_cdiv(C, 256), N), dim3(256), 0, stream, G, pm, arg, dx, HW, C, J);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+}   // extern "C"

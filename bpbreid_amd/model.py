@@ -199,12 +199,15 @@ class BPBreID(nn.Module):
         if m.dim_reduce not in ('none', 'before_pooling', 'after_pooling', 'before_and_after_pooling'):
             raise NotImplementedError("dim_reduce=%r: 'after_pooling_with_dropout' crashes in the reference (nn.opout, "
                                       'bpbreid.py:337)' % (m.dim_reduce,))
-        if m.pooling not in ('gwap', 'gap') or m.normalization != 'identity':
-            # 'gmp' (GlobalMaxPoolingHead, bpbreid.py:481-482: max over pixels of mask * feature) and the BatchNorm
-            # normalisations of the materialised [N*K, C, H, W] product are not offered
-            raise NotImplementedError("accelerated path: pooling in ('gwap', 'gap'), normalization='identity'; got %r / %r"
+        if m.pooling not in ('gwap', 'gap', 'gmp') or m.normalization != 'identity':
+            # the BatchNorm normalisations of the materialised [N*K, C, H, W] product (bpbreid.py:444-456; "obsolete",
+            # default_config.py:46) are not offered
+            raise NotImplementedError("accelerated path: pooling in ('gwap', 'gap', 'gmp'), normalization='identity'; got %r / %r"
                                       % (m.pooling, m.normalization))
         self.parts_gap = m.pooling == 'gap'
+        self.parts_gmp = m.pooling == 'gmp'      # GlobalMaxPoolingHead (bpbreid.py:481-482): csrc/maxpool_head.hip
+        if self.parts_gmp and m.masks.parts_num > 9:
+            raise NotImplementedError("pooling='gmp' is instantiated for up to 9 parts")
         if m.test_use_target_segmentation not in ('none', 'soft', 'hard'):
             raise ValueError('test_use_target_segmentation must be none, soft or hard')
         if pretrained:
@@ -443,6 +446,9 @@ class _ModelPlan:
         self.pool_part = f(n * self.nchunks * max(J, K1) * Cc)
         self.pooled = f(n, J, Cc)
         self.zinv = f(n, J)
+        if model.parts_gmp:
+            self.argmax = torch.empty(n, K, Cc, device=device, dtype=torch.int32)
+            self.zinv_dl, self.zinv_dx = f(n, J), f(n, J)
         # dense stack buffers
         self.lin_g, self.lin_f, self.lin_b, self.lin_p = f(n, D), f(n, D), f(n, D), f(n, K, D)
         # backward scratch
@@ -619,8 +625,10 @@ class _ModelPlan:
         x = self.feats.buf
         fresh = None
         # head on the branch outputs, the concatenated map is never written (csrc/head_lowres.hip)?
-        # (its gradient kernel is instantiated for K + 1 <= 9 classes, csrc/head_lowres.hip: more parts take the materialised map)
-        low = (not m.materialize_spatial_features) and self._lowres_srcs is not None and self.K1 <= 9 and os.environ.get('BPB_LOWRES_HEAD', '1') != '0'
+        # (its gradient kernel is instantiated for K + 1 <= 9 classes, csrc/head_lowres.hip: more parts take the materialised map;
+        #  so does pooling = 'gmp': a maximum over pixels does not commute with the bilinear up-sampling of the branches)
+        low = ((not m.materialize_spatial_features) and self._lowres_srcs is not None and self.K1 <= 9 and not m.parts_gmp
+               and os.environ.get('BPB_LOWRES_HEAD', '1') != '0')
         if low and self.lr is None:
             self._init_lowres()
         self.low = low
@@ -716,6 +724,9 @@ class _ModelPlan:
             nv.call('bpb_masked_pool', x.data_ptr(), self.pm.data_ptr(), self.pool_part.data_ptr(), n, HW, Cc, J, None, s())
             nv.call('bpb_pool_finalize', self.pool_part.data_ptr(), self.pm.data_ptr(), self.pooled.data_ptr(),
                     self.zinv.data_ptr(), n, self.nchunks, J, HW, Cc, 1 if m.parts_gap else 0, 0, Cc, s())
+            if m.parts_gmp:          # the part rows become max_p m_k x (+ arg-max pixels for the backward pass)
+                nv.call('bpb_masked_maxpool_fwd', x.data_ptr(), self.pm.data_ptr(), self.pooled.data_ptr(), self.argmax.data_ptr(),
+                        self.zinv.data_ptr(), self.zinv_dl.data_ptr(), self.zinv_dx.data_ptr(), n, HW, Cc, J, s())
         # ---- after-pooling dim reduce (Linear + BN1d + ReLU); pooled rows: 0 global, 1 fg, 2 bg, 3.. parts
         o = {}
         f = lambda *sh: _f32(*sh, device=dev)
@@ -912,12 +923,15 @@ class _ModelPlan:
                         self.Hf, self.Wf, K1 + 1, s())
             else:
                 nv.call('bpb_pixel_dots', x.data_ptr(), gp_ptr + Cc * 4, J * Cc, Cc, None, self.Dd.data_ptr(), n, HW, Cc, K1 + 1, s())
+                if m.parts_gmp:      # part columns: only the channels whose maximum sits at the pixel contribute
+                    nv.call('bpb_masked_maxpool_bwd_dmask', x.data_ptr(), gp_ptr, self.argmax.data_ptr(), self.Dd.data_ptr(), n, HW, Cc, J, s())
             gpix = g['pix'].contiguous() if g['pix'] is not None else None
             # gradients of the continuous visibility scores (vis[n][k] = max_p prob_k, fgvis[n] = max_k vis[n][k]) join dlogit
             dvis = g['vis'].to(torch.float32).contiguous() if (not self.binary and g['vis'] is not None) else None
             dfg = g['fgvis'].to(torch.float32).contiguous() if (not self.binary and g['fgvis'] is not None) else None
             use_arg = dvis is not None or dfg is not None
-            nv.call('bpb_head_bwd_dlogits', self.Dd.data_ptr(), self.probs.data_ptr(), self.argpart.data_ptr(), self.zinv.data_ptr(),
+            nv.call('bpb_head_bwd_dlogits', self.Dd.data_ptr(), self.probs.data_ptr(), self.argpart.data_ptr(),
+                    (self.zinv_dl if m.parts_gmp else self.zinv).data_ptr(),
                     self.gp.data_ptr(), gpix.data_ptr() if gpix is not None else None, self.dlogit.data_ptr(), self.lpart.data_ptr(),
                     None, n, HW, K1, nv.ptr(dvis), nv.ptr(dfg), self.argpix.data_ptr() if use_arg else None, s())
             if low:
@@ -951,10 +965,13 @@ class _ModelPlan:
                     self.k2.data_ptr(), s())
             first = 1
         else:
-            nv.call('bpb_head_bwd_dx', x.data_ptr(), gpool.data_ptr(), self.pm.data_ptr(), self.zinv.data_ptr(),
+            nv.call('bpb_head_bwd_dx', x.data_ptr(), gpool.data_ptr(), self.pm.data_ptr(), (self.zinv_dx if m.parts_gmp else self.zinv).data_ptr(),
                     self.dlogit.data_ptr(), pc.classifier.weight.data_ptr(), pc.bn.weight.data_ptr(), self.pix_mean.data_ptr(),
                     self.pix_invstd.data_ptr(), self.k1.data_ptr(), self.k2.data_ptr(), self.feats.grad.data_ptr(), n, HW, Cc, K1,
                     0, s())
+            if m.parts_gmp:          # the part rows' gradient lands on their arg-max pixels
+                nv.call('bpb_masked_maxpool_bwd_dx', gpool.data_ptr(), self.pm.data_ptr(), self.argmax.data_ptr(), self.feats.grad.data_ptr(),
+                        n, HW, Cc, J, s())
             if gfe is not None:          # the map is handed out as an NCHW view of the NHWC plan buffer: the gradient goes the same way
                 gn = gfe.to(torch.float32).permute(0, 2, 3, 1).contiguous()
                 nv.same_device(gn, 'BPBreID.backward')

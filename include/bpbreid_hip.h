@@ -447,6 +447,15 @@ int bpb_pool_finalize(const float* part, const float* pm, float* pooled, float* 
 int bpb_pool_finalize_multi(const float* const* part, const int* nchunks, const int* C, const int* c0, int nb, const float* pm,
                             float* pooled, float* zinv, int N, int J, int HW, int parts_gap, int Ct, hipStream_t stream);
 /* (`part` holds the channels [c0, c0 + C) of the Ct pooled channels: c0 = 0, Ct = C for a materialised map) */
+/* pooling = 'gmp' (GlobalMaxPoolingHead, torchreid/models/bpbreid.py:481-482 via :458-468: AdaptiveMaxPool2d over the materialised
+ * mask x feature product): pooled[n][3+k][c] = max_p m_k[p] x[p][c] on a materialised map x [N][HW][C], arg-max pixels kept in
+ * arg [N][K][C] (first maximum in scan order, like ATen).  `zinv_dl` / `zinv_dx` replace zinv in bpb_head_bwd_dlogits / bpb_head_bwd_dx:
+ * the mask gradient of a part row is D itself, the dense dx kernel leaves the part rows to bpb_masked_maxpool_bwd_dx.
+ * Backward = routing to the arg-max pixel (csrc/maxpool_head.hip); no [N,K,C,H,W] tensor, fixed summation order. */
+int bpb_masked_maxpool_fwd(const float* x, const float* pm, float* pooled, int* arg, const float* zinv, float* zinv_dl, float* zinv_dx,
+                           int N, int HW, int C, int J, hipStream_t stream);
+int bpb_masked_maxpool_bwd_dmask(const float* x, const float* G, const int* arg, float* D, int N, int HW, int C, int J, hipStream_t stream);
+int bpb_masked_maxpool_bwd_dx(const float* G, const float* pm, const int* arg, float* dx, int N, int HW, int C, int J, hipStream_t stream);
 int bpb_rowdot(const float* a, const float* b, float* out, int rows, int C, hipStream_t stream);
 int bpb_head_bwd_dlogits(const float* D, const float* probs, const unsigned char* argpart, const float* zinv,
                          const float* gp, const float* dlogit_ext, float* dlogit, double* lpart, int* nblocks_out, int N,

@@ -890,3 +890,43 @@ def test_grouped_gemm_against_float64():
     with pytest.raises(nv.NativeError):                # a join onto a predecessor of another shape
         probs[1].join = 1
         nv.call('bpb_gemm_grouped', probs, 8, None, 0, C.byref(need), None)
+
+
+@pytest.mark.parametrize('shape', [(3, 8 * 4, 72, 3), (2, 24 * 8 + 5, 200, 9), (2, 2304, 96, 5)])
+def test_masked_maxpool_head_against_autograd(shape):
+    """pooling = 'gmp' (bpbreid.py:481-482: AdaptiveMaxPool2d over the materialised mask x feature product): forward values,
+    arg-max pixels, and the two backward kernels (mask side, feature side) against PyTorch autograd of max over pixels on the CPU in
+    fp64 (tie-free random data: the sub-gradient is unique).  csrc/maxpool_head.hip; no [N,K,C,H,W] tensor on the GPU side."""
+    n, hw, c, k = shape
+    j = k + 3
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(n, hw, c, generator=g) - 0.2                       # NHWC pixels, some negative features
+    pm = torch.rand(n, j, hw, generator=g)
+    G = torch.randn(n, j, c, generator=g)
+    zinv = torch.rand(n, j, generator=g) + 0.5
+    xd, pmd, Gd, zd = (t.to(DEV) for t in (x, pm, G, zinv))
+    pooled = torch.full((n, j, c), 123.0, device=DEV)
+    arg = torch.empty(n, k, c, device=DEV, dtype=torch.int32)
+    zdl, zdx = torch.empty(n, j, device=DEV), torch.empty(n, j, device=DEV)
+    nv.call('bpb_masked_maxpool_fwd', xd.data_ptr(), pmd.data_ptr(), pooled.data_ptr(), arg.data_ptr(), zd.data_ptr(), zdl.data_ptr(),
+            zdx.data_ptr(), n, hw, c, j, nv.stream())
+    x64 = x.double().requires_grad_(True)
+    m64 = pm.double().requires_grad_(True)
+    prod = m64[:, 3:].unsqueeze(3) * x64.unsqueeze(1)                 # [n, k, hw, c]
+    ref, ref_arg = prod.max(dim=2)
+    assert torch.equal(arg.cpu().long(), ref_arg)
+    assert torch.equal(pooled[:, 3:].cpu(), (pm[:, 3:].unsqueeze(3) * x.unsqueeze(1)).max(dim=2)[0])     # the same fp32 products
+    assert bool((pooled[:, :3] == 123.0).all()), 'the mean rows are not this kernel\'s'
+    assert torch.equal(zdl.cpu()[:, :3], zinv[:, :3]) and bool((zdl[:, 3:] == -1).all()) and bool((zdx[:, 3:] == 0).all())
+    (ref * G[:, 3:].double()).sum().backward()
+    D = torch.full((n, hw, k + 2), 7.0, device=DEV)
+    nv.call('bpb_masked_maxpool_bwd_dmask', xd.data_ptr(), Gd.data_ptr(), arg.data_ptr(), D.data_ptr(), n, hw, c, j, nv.stream())
+    assert bool((D[:, :, :2] == 7.0).all()), 'fg / bg columns belong to bpb_pixel_dots'
+    assert rel_err(D[:, :, 2:].permute(0, 2, 1), m64.grad[:, 3:]) < 2e-6
+    dx = torch.randn(n, hw, c, generator=g).to(DEV)
+    before = dx.clone()
+    nv.call('bpb_masked_maxpool_bwd_dx', Gd.data_ptr(), pmd.data_ptr(), arg.data_ptr(), dx.data_ptr(), n, hw, c, j, nv.stream())
+    assert rel_err(dx - before, x64.grad) < 2e-6
+    dx2 = before.clone()
+    nv.call('bpb_masked_maxpool_bwd_dx', Gd.data_ptr(), pmd.data_ptr(), arg.data_ptr(), dx2.data_ptr(), n, hw, c, j, nv.stream())
+    assert torch.equal(dx, dx2), 'fixed summation order: repeated launches are bit-identical'

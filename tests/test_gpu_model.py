@@ -26,7 +26,11 @@ DEV = torch.device('cuda', 0)
 # one near-tie flip of the (non-differentiable) arg-max part under fp32 round-off moves 1/1024 of the data, and
 # BatchNorm populations of 4..32 elements amplify round-off: there the check is a cosine over all sampled elements.
 WELL_CONDITIONED = ('hr32_k5', 'hr32_k5_full', 'r50_k5_full', 'hr48_k8', 'hrw16_k5_float_vis', 'hrw16_k3_shared', 'hrw16_k5_soft',
-                    'hrw16_k5_hard', 'hrw16_k5_nolearn', 'hrw16_k5_before', 'hrw16_k5_gap')
+                    'hrw16_k5_hard', 'hrw16_k5_nolearn', 'hrw16_k5_before', 'hrw16_k5_gap', 'hrw16_k5_gmp',
+                    # round 4: the 256x128 ResNet-50 K=2 fixtures measure 0-2 of ~180 parameters outside the contract bound, none outside
+                    # the wide one, median error 0.8-1.5x the reference's noise -- held to the same rule (the loose rule below is left
+                    # for the 64x32 hrnet_w8 fixtures only, each of which has a 128x64 twin in this list)
+                    'r50_k2', 'r50_k2_soft', 'r50_k2_hard', 'r50_k2_nolearn', 'r50_k2_before', 'r50_k2_before_after')
 MODEL_CASES = {
     'hrw8_k5': ('hrnet_w8', {}),
     'hrw8_k5_float_vis': ('hrnet_w8', {'training_binary_visibility_score': False, 'testing_binary_visibility_score': False}),
@@ -53,6 +57,7 @@ MODEL_CASES = {
     'hrw16_k5_nolearn': ('hrnet_w16', {'learnable_attention_enabled': False}),
     'hrw16_k5_before': ('hrnet_w16', {'dim_reduce': 'before_pooling'}),
     'hrw16_k5_gap': ('hrnet_w16', {'pooling': 'gap'}),
+    'hrw16_k5_gmp': ('hrnet_w16', {'pooling': 'gmp'}),        # round 4: GlobalMaxPoolingHead (csrc/maxpool_head.hip)
 }
 WEIGHTS_MARKET = {'globl': {'id': 1., 'tr': 0.}, 'foreg': {'id': 1., 'tr': 1.}, 'conct': {'id': 1., 'tr': 0.},
                   'parts': {'id': 0., 'tr': 1.}, 'pixls': {'ce': 0.35}}
@@ -66,7 +71,8 @@ WEIGHTS_DEFAULT = {'globl': {'id': 1., 'tr': 0.}, 'foreg': {'id': 1., 'tr': 0.},
 # target-segmentation fixtures apply running statistics of train-mode embeddings to differently masked eval embeddings: dead
 # ReLU features (running variance ~0) amplify the difference by 1/sqrt(eps) = 316, same wider bound.
 TIGHT = ('hr32_k5', 'hr32_k5_full', 'r50_k2', 'r50_k5_full', 'hr48_k8', 'r50_k2_nolearn', 'r50_k2_before', 'r50_k2_before_after',
-         'hrw16_k5_float_vis', 'hrw16_k3_shared', 'hrw16_k5_soft', 'hrw16_k5_hard', 'hrw16_k5_nolearn', 'hrw16_k5_before', 'hrw16_k5_gap')
+         'hrw16_k5_float_vis', 'hrw16_k3_shared', 'hrw16_k5_soft', 'hrw16_k5_hard', 'hrw16_k5_nolearn', 'hrw16_k5_before', 'hrw16_k5_gap',
+         'hrw16_k5_gmp')
 
 
 def close(got, ref32, ref64, c=4.0, rel=1e-4, what=''):
@@ -133,7 +139,9 @@ def check_ranking(dm, z):
 
 # every HRNet fixture whose head reads the concatenated map directly (no 1x1 dimension reduction in front of it) is also run with
 # the head on the branch outputs (model.materialize_spatial_features = False, csrc/head_lowres.hip): same goldens, same bounds
-LOWRES_CASES = [nm for nm, (bb, ex) in MODEL_CASES.items() if bb.startswith('hrnet') and 'before' not in ex.get('dim_reduce', '')]
+# (not 'gmp': a maximum over pixels does not commute with the up-sampling of the branches, the model keeps the materialised map)
+LOWRES_CASES = [nm for nm, (bb, ex) in MODEL_CASES.items() if bb.startswith('hrnet') and 'before' not in ex.get('dim_reduce', '')
+                and ex.get('pooling') != 'gmp']
 
 
 @pytest.mark.parametrize('name,lowres', [(nm, False) for nm in MODEL_CASES] + [(nm, True) for nm in LOWRES_CASES])
