@@ -331,10 +331,8 @@ class Net:
                 return _cdiv(n, ti_) * _cdiv(h, th_) * _cdiv(w, tw_) * _cdiv(cout, (32 * nt_) << lwn_)
             if r == 3 and in_region:
                 mt_r, nt, lwn = 1, 1, 0
-                # (experimental, needs the library of tools/s1_mixed.py: csrc/experimental/conv_s1_mixed.hip) the shallow wide
-                # branches take two pixel sub-tiles per wave and still share the launch of the deep ones
-                if os.environ.get('BPB_S1_MIXED', '0') == '1' and k2 <= int(os.environ.get('BPB_S1_MIXED_MAX', '288')) and wgs(2, 1, 0) >= int(os.environ.get('BPB_S1_MIXED_MINWG', '256')):
-                    mt_r = 2
+                # (round 3's mixed-tile variant -- two pixel sub-tiles per wave for the shallow wide branches inside the same launch --
+                #  measured -6 % / -2 % / 0 % on the two- / three- / four-branch launches, profiles/r03_s1_mixed_first.txt: removed)
             elif r == 3:
                 # a launch of its own: the largest wave tile that still gives two workgroups per CU (tools/s1_sweep.py:
                 # 64->64 @64x32 118 TFLOP/s with 64x64 wave tiles, 128->128 @16x8 only 31 with them but 90 with 32x32)
@@ -528,8 +526,7 @@ class Net:
     def _conv_rec(self, prob, label):
         """Launch record of one convolution problem (either kernel)."""
         if isinstance(prob, ConvS1Prob):
-            mixed = os.environ.get('BPB_S1_MIXED', '0') == '1' and prob.R == 3 and prob.nt == 1 and prob.lwn == 0
-            kind, key = nv.OP_CONV_S1, ('s1', prob.nt, 'any' if mixed else prob.mt_r, prob.R, prob.CK)
+            kind, key = nv.OP_CONV_S1, ('s1', prob.nt, prob.mt_r, prob.R, prob.CK)
             variant = 'bpb_conv_s1_kernel<%d,%d,%d,%d>' % (prob.nt, prob.mt_r, prob.R, prob.CK // 8)
             npix, taps, cin_in = prob.N * prob.H * prob.W, prob.R * prob.R, prob.N * prob.H * prob.W * prob.Cin
             blocks = prob.n_mtiles * prob.n_ntiles

@@ -10,8 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# (BPB_LIB_PATH: measurement builds only -- tools/s1_trace.py, tools/s1_mixed.py link variants of single kernels into a library of
-#  their own; the product always loads the in-tree libbpbreid_hip.so)
+# (BPB_LIB_PATH: measurement builds only -- tools/s1_trace.py links the phase-stamping build of conv_s1.hip into a library of its
+#  own; the product always loads the in-tree libbpbreid_hip.so)
 LIB_PATH = os.environ.get('BPB_LIB_PATH') or os.path.join(_HERE, 'libbpbreid_hip.so')
 
 c_fp = C.c_void_p

@@ -152,49 +152,6 @@ def test_grouped_conv_policies_k_split_unpadded_halo_transposed_epilogue(monkeyp
     assert any(p.split for p in fwd) and any(p.split for p in dgrad)
 
 
-def test_experimental_mixed_tile_policy_descriptors(monkeypatch):
-    """BPB_S1_MIXED=1 (experimental, tools/s1_mixed.py; csrc/experimental/conv_s1_mixed.hip is NOT part of the product library): the
-    shallow wide branches of a module step take two pixel sub-tiles per wave, staged unpadded so that four workgroups still fit a
-    CU, and share the launch of the deep ones -- 1280 instead of 2048 workgroups for the four-branch step.  Descriptor geometry of
-    such a problem through the kernel emulator.  Without the switch nothing changes (every other test of this file)."""
-    monkeypatch.setenv('BPB_S1_MIXED', '1')
-    net = Net(torch.device('cpu'))
-    branches = [(64, 32, 32), (32, 16, 64), (16, 8, 128), (8, 4, 256)]
-    net.fork(4)
-    for i, (h, w, c) in enumerate(branches):
-        net.set_slot(i)
-        wt = torch.zeros(c, c, 3, 3)
-        wt.grad = torch.zeros_like(wt)
-        net.conv(Act(net, 64, h, w, c), wt, 1, 1)
-    net.set_slot(0)
-    net.join(4)
-    net.finalize(False)
-    by_c = {p.Cin: p for p, *_ in net.debug_convs}
-    assert [by_c[c].mt_r for c in (32, 64, 128, 256)] == [2, 2, 1, 1]
-    assert all(by_c[c].LD == by_c[c].CK for c in (32, 64)) and by_c[256].split and not by_c[32].split
-    lds = lambda p: 2 * (((1 << p.lTI) * p.HH * p.HW * (p.LD // 4) + 3) // 4 * 4 + 9 * (p.CK // 4) * 32) * 16
-    assert max(lds(p) for p in by_c.values()) <= 160 * 1024 // 4                     # four workgroups per CU
-    ops = [(o, m) for o, m in zip(net.plan_eval[0], net.plan_eval[2]) if m['label'].startswith('conv_fwd')]
-    assert len(ops) == 1 and ops[0][0].i[0] == 4 and ops[0][0].i[1] == 512 + 256 + 256 + 2 * 128
-    # geometry of a two-tile, unpadded problem
-    g = torch.Generator().manual_seed(3)
-    n, h, w, cin, cout = 8, 96, 96, 8, 8
-    wt = torch.randn(cout, cin, 3, 3, generator=g, dtype=torch.float64)
-    xin = torch.randn(n, cin, h, w, generator=g, dtype=torch.float64)
-    net = Net(torch.device('cpu'))
-    net.fork(2)
-    wp = wt.float().clone()
-    wp.grad = torch.zeros_like(wp)
-    net.conv(Act(net, n, h, w, cin), wp, 1, 1, bn=None)
-    net.join(2)
-    net.finalize(False)
-    p = net.debug_convs[0][0]
-    assert (p.mt_r, p.LD) == (2, p.CK)
-    y = np.zeros((n, h, w, cout))
-    emu.run_conv_s1(p, xin.permute(0, 2, 3, 1).numpy().copy(), emu.pack_fwd(wt.numpy(), cin), y)
-    assert np.allclose(y, F.conv2d(xin, wt, padding=1).permute(0, 2, 3, 1).numpy(), atol=1e-9)
-
-
 @pytest.mark.parametrize('case', CONV_CASES)
 def test_conv_descriptors_forward_dgrad_wgrad(case):
     n, h, w, cin, cout, k, stride, pad = case

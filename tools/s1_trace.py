@@ -18,7 +18,7 @@ NA = os.environ.get('S1_NA', '1')
 tag = '' if (ABL, NA) == ('0', '1') else '_abl%s_na%s' % (ABL, NA)
 trace_lib = os.path.join(objdir, 'libbpbreid_hip_trace%s.so' % tag)
 trace_obj = os.path.join(objdir, 'conv_s1_trace%s.o' % tag)
-src = os.environ.get('S1_TRACE_SRC') or os.path.join(B.CSRC, 'conv_s1.hip')       # (S1_TRACE_SRC: csrc/experimental/conv_s1_mixed.hip)
+src = os.environ.get('S1_TRACE_SRC') or os.path.join(B.CSRC, 'conv_s1.hip')
 if os.environ.get('S1_TRACE_SRC'):
     tag += '_' + os.path.splitext(os.path.basename(src))[0]
     trace_lib = os.path.join(objdir, 'libbpbreid_hip_trace%s.so' % tag)
