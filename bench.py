@@ -47,9 +47,11 @@ def parse():
                     'when that does not finish inside its time budget)')
     ap.add_argument('--no-forward-only', action='store_true')
     ap.add_argument('--no-eval', action='store_true')
-    ap.add_argument('--graph', type=int, default=0,
-                    help='1: replay the step from one hipGraph (same kernel time, ~1 ms instead of 20-28 ms of host work per step; '
-                         'with --gpus N the RCCL all-reduce launches are captured with the step)')
+    ap.add_argument('--graph', type=int, default=-1,
+                    help='1: replay the step from one hipGraph (8 instead of 21 ms of host work per step; with --gpus N the RCCL '
+                         'all-reduce launches are captured with the step and the ranks AGREE on graph vs eager); 0: eager launches '
+                         '(the weight gradients then run on a side stream: 30.8 instead of 32.8 ms per step on one GPU); -1 (default): '
+                         'eager, unless the slowest rank\'s host loop needs more than 85 %% of the step -- then the graph')
     ap.add_argument('--dist-backend', default='nccl', help="'nccl' (= RCCL over xGMI; the default) or 'gloo' (functional check of the "
                     "multi-process path when the ranks have to share one GPU)")
     ap.add_argument('--dump-plan-timing', default='', help='write the per-record isolated timings of the forward and backward '
@@ -430,18 +432,30 @@ def main():
     for _ in range(args.warmup):
         loss, _ = step()
     torch.cuda.synchronize()
-    if args.graph and (not multi or args.dist_backend == 'nccl'):     # (RCCL collectives are captured with the step)
-        try:
-            replay = eng.capture_step(data, warmup=1)
-            step = lambda: replay()
-            loss, _ = step()
-            torch.cuda.synchronize()
-            mode = 'hipgraph'
-        except Exception as ex:                        # capture is an optimisation; never fail the benchmark on it
-            sys.stderr.write('hipGraph capture failed, using eager launches: %r\n' % (ex,))
-            step = lambda: eng.forward_backward(data)
-            loss, _ = step()
-            torch.cuda.synchronize()
+    want_graph = args.graph == 1
+    host_bound = None
+    if args.graph == -1 and (not multi or args.dist_backend == 'nccl'):
+        # eager is the faster schedule while the host keeps up (two-stream backward); a host loop that needs > 85 % of the step on
+        # ANY rank (few cores per rank) makes the job host-bound: all ranks then switch to the captured step together
+        probe = 3
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(probe):
+            step()
+        t_host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        ratio = torch.tensor([t_host / max(time.perf_counter() - t0, 1e-9)], device=dev, dtype=torch.float64)
+        if multi:
+            dist.all_reduce(ratio, op=dist.ReduceOp.MAX)
+        host_bound = float(ratio)
+        want_graph = host_bound > 0.85
+    if want_graph and (not multi or args.dist_backend == 'nccl'):     # (RCCL collectives are captured with the step)
+        replay, mode, why = eng.capture_step_agreed(data, warmup=1)
+        if why:
+            sys.stderr.write('hipGraph capture not used (%s): eager launches on every rank\n' % why)
+        step = lambda: replay()
+        loss, _ = step()
+        torch.cuda.synchronize()
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
@@ -455,9 +469,10 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if multi:
-        t = torch.tensor([elapsed, host_enqueue], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed, host_enqueue, -host_enqueue], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, host_enqueue = float(t[0]), float(t[1])      # the slowest rank sets the step; the busiest host loop is reported
+        elapsed, host_enqueue, host_enqueue_min = float(t[0]), float(t[1]), -float(t[2])    # the slowest rank sets the step; the
+                                                                                            # busiest / idlest host loops are reported
     final_loss = float(loss.detach())
     exchange = None
     if multi:
@@ -503,6 +518,8 @@ def main():
                                % (args.backbone, args.parts, args.height, args.width, args.batch, args.batch * world),
                    'parallelism': 'dp%d' % world, 'global_batch': args.batch * world, 'final_loss': final_loss,
                    'host_enqueue_ms_per_step': 1e3 * host_enqueue / args.steps, 'launch_mode': mode,
+                   'host_enqueue_ms_per_step_min_over_ranks': 1e3 * (host_enqueue_min if multi else host_enqueue) / args.steps,
+                   'host_fraction_of_step_before_choosing_the_launch_mode': host_bound,
                    'host_cores_per_rank': len(pinned) if pinned else host_cores(),
                    'backbone_launches_per_step': sum(p_[1] for p_ in (next(iter(model._plans.values())).net.plan_train,
                                                                        next(iter(model._plans.values())).net.plan_bwd))},

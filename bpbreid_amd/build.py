@@ -20,12 +20,15 @@ def _stale():
 
 
 def source_id():
-    """Content hash of the kernel sources (csrc/ + the C-ABI header): stamps measurement files (profiles/*_pmc_hbm.json) so that
+    """Content hash of the kernel sources (csrc/ + the C-ABI header) and of the launch-plan policy (graph.py, model.py,
+    backbones.py, native.py): stamps measurement files (profiles/*_pmc_hbm.json) so that
     a figure taken from another build is recognised as stale (the GPU box has no .git to ask for a commit hash)."""
     import hashlib
     h = hashlib.sha256()
-    for path in sorted([os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, 'bpb_common.h'),
-                                                                    os.path.join(HERE, '..', 'include', 'bpbreid_hip.h')]):
+    # (+ the plan compiler and the model glue: tile / split / stream policies decide how many bytes a launch moves)
+    policy = [os.path.join(HERE, f) for f in ('graph.py', 'model.py', 'backbones.py', 'native.py')]
+    for path in sorted([os.path.join(CSRC, s) for s in SOURCES] + policy + [os.path.join(CSRC, 'bpb_common.h'),
+                                                                             os.path.join(HERE, '..', 'include', 'bpbreid_hip.h')]):
         if os.path.exists(path):
             h.update(os.path.basename(path).encode())
             h.update(open(path, 'rb').read())

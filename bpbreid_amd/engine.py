@@ -162,26 +162,31 @@ class ImagePartBasedEngine:
                         set(self.optimizer.updated))
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                self.forward_backward(static)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.check_handovers()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            loss, summary = self.forward_backward(static)
-        # nothing of the above is training: restore the snapshot (the captured launches did not execute; the host-side step
-        # counter was advanced by the warm-up and by the capture pass)
-        for k, v in snap.items():
-            arena[k].copy_(v)
-        if fused:
-            self.optimizer.exp_avg.copy_(snap_opt[0])
-            self.optimizer.exp_avg_sq.copy_(snap_opt[1])
-            self.optimizer.step_index = snap_opt[2]
-            self.optimizer.step_dev.fill_(snap_opt[2])
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    self.forward_backward(static)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.check_handovers()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                loss, summary = self.forward_backward(static)
             captured = {k for k, p in enumerate(arena['params']) if p.grad is not None}
-            self.optimizer.updated = snap_opt[3]
+        finally:
+            # nothing of the above is training, whether the capture succeeded or not: restore the snapshot (the captured launches did
+            # not execute; the host-side step counter was advanced by the warm-up and by the capture pass)
+            torch.cuda.synchronize()
+            for k, v in snap.items():
+                arena[k].copy_(v)
+            if hasattr(self.model, 'bump_param_version'):
+                self.model.bump_param_version()
+            if fused:
+                self.optimizer.exp_avg.copy_(snap_opt[0])
+                self.optimizer.exp_avg_sq.copy_(snap_opt[1])
+                self.optimizer.step_index = snap_opt[2]
+                self.optimizer.step_dev.fill_(snap_opt[2])
+                self.optimizer.updated = snap_opt[3]
 
         def replay(new_data=None):
             if new_data is not None:
@@ -203,6 +208,34 @@ class ImagePartBasedEngine:
 
         self._graph = graph
         return replay
+
+    def capture_step_agreed(self, data, warmup=3):
+        """capture_step for a data-parallel job: every rank tries to capture, then ONE MIN all-reduce of an ok flag decides for
+        everybody -- all ranks replay their graphs, or all ranks launch eagerly.  (A rank replaying a graph that holds the RCCL
+        launches while another one issues them eagerly is fine for RCCL, but a rank that failed to capture and silently fell back
+        must not leave the others believing otherwise: the decision, and its reason, are the same on every rank.)
+        Returns (step(new_data=None) -> (loss, loss_summary), 'hipgraph' | 'eager', error text or None)."""
+        import torch.distributed as dist
+        err, replay = None, None
+        try:
+            replay = self.capture_step(data, warmup=warmup)
+        except Exception as ex:                          # capture is an optimisation: never fatal
+            err = repr(ex)
+        ok = torch.tensor([1 if replay is not None else 0], dtype=torch.int32, device=next(self.model.parameters()).device)
+        if self.distributed and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
+            if dist.get_backend(self.process_group) != 'nccl':
+                ok = ok.cpu()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.process_group)
+        if int(ok.item()) == 1:
+            return replay, 'hipgraph', None
+        self._graph = None
+        last = {'data': data}
+
+        def eager(new_data=None):
+            if new_data is not None:
+                last['data'] = new_data
+            return self.forward_backward(last['data'])
+        return eager, 'eager', err or 'another rank could not capture the step'
 
     def combine_losses(self, visibility_scores_dict, embeddings_dict, id_cls_scores_dict, pids, pixels_cls_scores=None,
                        target_masks=None, bpa_weight=0):

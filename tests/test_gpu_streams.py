@@ -79,7 +79,11 @@ def test_captured_step_matches_the_eager_two_stream_step():
         with _Env(BPB_SIDE_STREAM='1'):
             model = Cm.fill_state_dict_(bpbreid(ncls, config=cfg, pretrained=False)).to(DEV)
             eng = ImagePartBasedEngine(model, optimizer=FusedAdam(model, lr=1e-3), losses_weights=WEIGHTS, mask_filtering_training=True)
-            step = eng.capture_step(data, warmup=2) if graph else (lambda: eng.forward_backward(data))
+            if graph:
+                step, mode, why = eng.capture_step_agreed(data, warmup=2)
+                assert mode == 'hipgraph' and why is None
+            else:
+                step = lambda: eng.forward_backward(data)
             out = []
             for _ in range(3):
                 loss, _ = step()
@@ -90,3 +94,36 @@ def test_captured_step_matches_the_eager_two_stream_step():
     l0, p0 = run(False)
     l1, p1 = run(True)
     assert l0 == l1 and torch.equal(p0, p1)
+
+
+def test_a_failed_capture_falls_back_to_eager_with_the_state_restored(monkeypatch):
+    """capture_step_agreed: a capture that raises (here: inside the captured pass) must leave parameters, BatchNorm buffers and the
+    optimizer state exactly as they were, and hand out an eager step -- the decision every rank of a data-parallel job takes together."""
+    k, d, n, h, w, ncls = 3, 64, 8, 64, 32, 16
+    cfg = Cm.make_cfg('hrnet_w8', k, d)
+    imgs, masks, pids = Cm.synth_batch(n, h, w, k, ncls)
+    data = {'image': imgs.to(DEV), 'mask': masks.to(DEV), 'pid': pids.to(DEV)}
+    model = Cm.fill_state_dict_(bpbreid(ncls, config=cfg, pretrained=False)).to(DEV)
+    eng = ImagePartBasedEngine(model, optimizer=FusedAdam(model, lr=1e-3), losses_weights=WEIGHTS, mask_filtering_training=True)
+    eng.forward_backward(data)
+    torch.cuda.synchronize()
+    before = {kk: model.arena()[kk].clone() for kk in ('param', 'fbuf', 'ibuf')}
+    step_index = eng.optimizer.step_index
+    real = eng.forward_backward
+    calls = {'n': 0}
+
+    def flaky(batch):
+        calls['n'] += 1
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('simulated capture failure')
+        return real(batch)
+    monkeypatch.setattr(eng, 'forward_backward', flaky)
+    step, mode, why = eng.capture_step_agreed(data, warmup=2)
+    assert mode == 'eager' and 'simulated capture failure' in why and calls['n'] == 3
+    torch.cuda.synchronize()
+    for kk, v in before.items():
+        assert torch.equal(model.arena()[kk], v), kk
+    assert eng.optimizer.step_index == step_index
+    monkeypatch.setattr(eng, 'forward_backward', real)
+    loss, _ = step()
+    assert torch.isfinite(loss)
