@@ -257,7 +257,7 @@ def pin_rank_to_cores(local, nranks):
 def dump_plan_timing(plan, path):
     net = plan.net
     out = {}
-    for name, pl in (('forward', net.plan_train), ('backward', net.plan_bwd)):
+    for name, pl in (('forward', net.plan_train), ('backward', net.plan_bwd), ('forward_eval', net.plan_eval)):
         arr, n, meta = pl
         rows = net.run_timed(pl)
         out[name] = [{'label': m['label'], 'kind': int(arr[k].kind), 'slot': int(arr[k].i[10]), 'i0': int(arr[k].i[0]),
