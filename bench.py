@@ -356,7 +356,7 @@ def eval_block(dev):
     """The evaluation path at BASELINE configs[4] size on this GPU (inputs resident in HBM): part-based distance with the per-part
     matrix [P,Q,G] written (torchreid/metrics/distance.py:87-247) and without it, CMC / mAP (rank.py:97-159) and the ranked index
     matrix (rank.py:110) of the distance matrix in HBM."""
-    from bpbreid_amd.metrics import compute_distance_matrix_using_bp_features, evaluate_rank
+    from bpbreid_amd.metrics import compute_distance_matrix_using_bp_features, evaluate_rank, argsort_rows_gpu
     Q, G, P, D = EVAL_SHAPE
     qf, gf, qv, gv, (qp, gp, qc, gc) = eval_inputs(dev)
 
@@ -377,11 +377,11 @@ def eval_block(dev):
     (dm, _), ms_plain = timed(lambda: dist_fn(False))
     flops = 2.0 * P * Q * G * D
     res, ms_rank = timed(lambda: evaluate_rank(dm, qp, gp, qc, gc, max_rank=50))
-    _, ms_sort = timed(lambda: evaluate_rank(dm, qp, gp, qc, gc, max_rank=50, return_indices=True))
+    _, ms_sort = timed(lambda: argsort_rows_gpu(dm))          # the ranked index matrix stays in HBM (its host copy is 164 MB of PCIe)
     return {'Q': Q, 'G': G, 'P': P, 'D': D, 'distance_ms': ms_parts, 'distance_tflops': flops / ms_parts * 1e-9,
             'distance_frac': flops / ms_parts * 1e-9 / PEAK_F32_MFMA_TFLOPS, 'distance_ms_without_part_matrix': ms_plain,
             'distance_frac_without_part_matrix': flops / ms_plain * 1e-9 / PEAK_F32_MFMA_TFLOPS, 'rank_ms': ms_rank,
-            'rank_plus_argsort_ms': ms_sort, 'argsort_ms': ms_sort - ms_rank, 'mAP': float(res['mAP']), 'rank1': float(res['cmc'][0])}
+            'argsort_ms': ms_sort, 'mAP': float(res['mAP']), 'rank1': float(res['cmc'][0])}
 
 
 def main():

@@ -26,9 +26,7 @@ extern "C" int bpb_plan_run(const BpbPlanOp* ops, int nops, hipStream_t stream)
     return 0;
 }
 
-// Two-stream variant (round 4).  i[10] == 2: a record of an ODD branch chain of a fork region (training forward, graph.py): the chains
-// of a region are independent of each other, so the odd ones run on `side`, ordered only behind the region's start, and the JOIN
-// marker that closes the region orders `main` behind them.  Records whose i[10] is 1 -- the weight-gradient launches, their slab reduces and the bias
+// Two-stream variant (round 4).  Records whose i[10] is 1 -- the weight-gradient launches, their slab reduces and the bias
 // column sums: consumers of tensors that are final when the record is reached (x of the forward pass, dy), producers of
 // tensors nobody on the plan reads (dW is read by the optimizer / the gradient exchange) -- are enqueued on `side`; everything
 // else stays on `main`.  Between dependent kernels of ONE stream the chip drains and refills (the tail of a grouped convolution
@@ -38,49 +36,26 @@ extern "C" int bpb_plan_run(const BpbPlanOp* ops, int nops, hipStream_t stream)
 //   end of the call:                 record(ev_join, side); wait(main, ev_join)      -- dW is final for whoever follows on main
 // A stream wait captures the event's state at the time of the call, so the two events can be re-recorded at every fork / join.
 // Streams and events belong to the caller (the library keeps no state); side == nullptr runs everything on `main`.
+// (Measured and NOT kept, round 4: the odd branch chains of the training forward's fork regions on the side stream -- 10.39 ->
+//  10.74 ms per forward, 30.7 -> 30.9 ms per step; an eval forward as two half-batch chains -- 7.76 -> 7.82 ms.  Two chains of the
+//  same kind want the matrix pipes at the same time; what pays is putting work of a DIFFERENT kind beside the chain.)
 extern "C" int bpb_plan_run2(const BpbPlanOp* ops, int nops, hipStream_t main, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join)
 {
     if (side == nullptr) return bpb_plan_run(ops, nops, main);
     BPB_REQUIRE(ev_fork != nullptr && ev_join != nullptr, "bpb_plan_run2: a side stream needs the fork and join events");
-    // main_ahead: `main` has launches the side stream has not been ordered behind; region_forked: the side stream has been ordered
-    // behind the start of the current fork region; side_pending: the side stream has launches `main` has not been ordered behind
-    bool main_ahead = true, region_forked = false, side_pending = false;
-    auto fork = [&]() -> int {
-        hipError_t e = hipEventRecord(ev_fork, main);
-        if (e == hipSuccess) e = hipStreamWaitEvent(side, ev_fork, 0);
-        return e == hipSuccess ? 0 : bpb_set_error((int)e, "bpb_plan_run2: fork: %s", hipGetErrorString(e));
-    };
-    auto join = [&]() -> int {
-        hipError_t e = hipEventRecord(ev_join, side);
-        if (e == hipSuccess) e = hipStreamWaitEvent(main, ev_join, 0);
-        return e == hipSuccess ? 0 : bpb_set_error((int)e, "bpb_plan_run2: join: %s", hipGetErrorString(e));
-    };
+    bool main_ahead = true, side_used = false;
     for (int k = 0; k < nops; ++k) {
         const BpbPlanOp& o = ops[k];
-        if (o.kind == BPB_OP_JOIN) {            // end of a fork region whose chains may have run on both streams
-            if (side_pending) {
-                if (int rc = join()) return rc;
-                side_pending = false;
-            }
-            region_forked = false;
-            continue;
-        }
-        if (o.kind == BPB_OP_FORK || o.kind == BPB_OP_DEP) continue;
+        if (o.kind == BPB_OP_FORK || o.kind == BPB_OP_JOIN || o.kind == BPB_OP_DEP) continue;
         int rc;
-        if (o.i[10] == 1) {                     // consumes what `main` produced up to here
+        if (o.i[10] == 1) {
             if (main_ahead) {
-                if ((rc = fork()) != 0) return rc;
+                hipError_t e = hipEventRecord(ev_fork, main);
+                if (e == hipSuccess) e = hipStreamWaitEvent(side, ev_fork, 0);
+                if (e != hipSuccess) return bpb_set_error((int)e, "bpb_plan_run2: fork: %s", hipGetErrorString(e));
                 main_ahead = false;
-                region_forked = true;
             }
-            side_pending = true;
-            rc = run_one(o, k, side);
-        } else if (o.i[10] == 2) {              // a branch chain of a fork region: independent of the region's other chains
-            if (!region_forked) {
-                if ((rc = fork()) != 0) return rc;
-                region_forked = true;
-            }
-            side_pending = true;
+            side_used = true;
             rc = run_one(o, k, side);
         } else {
             main_ahead = true;
@@ -88,7 +63,12 @@ extern "C" int bpb_plan_run2(const BpbPlanOp* ops, int nops, hipStream_t main, h
         }
         if (rc != 0) return rc;
     }
-    return side_pending ? join() : 0;
+    if (side_used) {
+        hipError_t e = hipEventRecord(ev_join, side);
+        if (e == hipSuccess) e = hipStreamWaitEvent(main, ev_join, 0);
+        if (e != hipSuccess) return bpb_set_error((int)e, "bpb_plan_run2: join: %s", hipGetErrorString(e));
+    }
+    return 0;
 }
 
 // Events for bpb_plan_run2 (timing disabled: cheapest record / wait).  The caller owns the handle.

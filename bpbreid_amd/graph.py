@@ -187,10 +187,6 @@ class Net:
         # weight-gradient launches (+ their slab reduces) of the backward plan on a second stream (csrc/plan.cpp: bpb_plan_run2)
         self.side_stream = os.environ.get('BPB_SIDE_STREAM', '1') != '0'
         self._side = None                  # (torch stream, fork event, join event), created on first use
-        # training forward: the odd branch chains of every fork region on the second stream (complementary kernels side by side: the
-        # convolution launch of one half next to the BatchNorm apply pass of the other)
-        self.fwd_streams = os.environ.get('BPB_FWD_STREAMS', '0') == '1'
-        self._split_merge = False          # (set while the training-forward plan is being merged)
 
     # ------------------------------------------------------------------ graph construction
     def _node(self, kind, payload):
@@ -827,8 +823,6 @@ class Net:
         units = [u for u in units if u[0].kind not in (OP_NONE, OP_ALIGN)]
         for u in units:
             key = u[0].key if (u[0].key is not None and self.grouped) else ('single', id(u[0]))
-            if self._split_merge and u[0].key is not None and self.grouped:
-                key = key + (u[0].slot & 1,)         # chains of the two streams never share a launch
             buckets.setdefault(key, []).extend(u if self.grouped or u[0].key is None else u[:1])
             if not self.grouped and u[0].key is not None:
                 for extra in u[1:]:
@@ -877,26 +871,18 @@ class Net:
                 for s_ in go:
                     pos[s_] += 1
                 self._emit_groups(groups, heads)
-            if self._split_merge:                        # the region's chains ran on two streams: whoever follows needs both
-                groups.append([Rec(nv.OP_JOIN, 'join', op=self._op(nv.OP_JOIN))])
             k = j + 1
         return groups
 
     def _freeze(self, recs, name=None):
         """Turn the records into the PlanOp array that bpb_plan_run walks.  Returns (array, count, meta per launch)."""
-        self._split_merge = bool(self.fwd_streams and name == 'train')
         groups = self._merge(self._balance(recs))
-        split, self._split_merge = self._split_merge, False
         if name is not None:
             self.plan_groups[name] = groups
         arr = (PlanOp * max(1, len(groups)))()
         meta = []
         for k, g in enumerate(groups):
-            # stream of the launch (csrc/plan.cpp: bpb_plan_run2): 1 = side stream after everything enqueued so far on the main one
-            # (weight gradients), 2 = side stream, ordered only behind the region's fork (an odd branch chain of a fork region)
             side = 1 if (self.side_stream and all(r_.side for r_ in g)) else 0
-            if split and g[0].kind not in (nv.OP_FORK, nv.OP_JOIN) and all(r_.slot & 1 for r_ in g):
-                side = 2
             if g[0].op is not None:
                 assert len(g) == 1
                 arr[k] = g[0].op
@@ -1346,8 +1332,7 @@ class Net:
             ops = C.c_void_p(C.addressof(arr) + begin * C.sizeof(PlanOp))
             # (not under hipGraph capture: the replay of a graph with the cross-stream edges measured SLOWER than the one-stream
             #  graph, 33.7 vs 32.8 ms per step and 21 instead of 8 ms of host time per replay, gpurun_out/r04a)
-            two = (self.side_stream and plan is getattr(self, 'plan_bwd', None)) or (self.fwd_streams and plan is getattr(self, 'plan_train', None))
-            if two and not torch.cuda.is_current_stream_capturing():
+            if self.side_stream and plan is getattr(self, 'plan_bwd', None) and not torch.cuda.is_current_stream_capturing():
                 side, ev_fork, ev_join = self._side_objects()
                 nv.call('bpb_plan_run2', ops, end - begin, nv.stream(), C.c_void_p(side.cuda_stream), ev_fork, ev_join)
             else:

@@ -516,7 +516,7 @@ def test_two_rank_data_parallel_matches_single_process(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     common = ['--steps', '3', '--warmup', '0', '--backbone', 'hrnet_w8', '--batch', '16', '--height', '128', '--width', '64',
-              '--classes', '32', '--no-cpu-baseline', '--no-roofline', '--no-forward-only', '--no-eval', '--same-data']
+              '--classes', '32', '--no-cpu-baseline', '--no-roofline', '--no-forward-only', '--no-eval', '--same-data', '--graph', '0']
     env = dict(os.environ)
     for kk in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(kk, None)
