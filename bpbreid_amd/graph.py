@@ -26,7 +26,7 @@ import os
 import torch
 
 from . import native as nv
-from .native import (BnEvalDesc, ConvProb, ConvS1Prob, WgradProb, PackProb, FuseArgs, TermBwdArgs, BilinearArgs, BnFinDesc,
+from .native import (BnEvalDesc, ConvProb, ConvS1Prob, ConvS1wProb, WgradProb, PackProb, FuseArgs, TermBwdArgs, BilinearArgs, BnFinDesc,
                      BnBwdFinDesc, WgradReduceDesc, BilinearBwdDesc, Wgrad1x1Prob, PlanOp, magic)
 
 OP_NONE = -1                 # placeholder record: takes part in the lock-step merge, is never launched
@@ -182,6 +182,7 @@ class Net:
         self.merge_identity = os.environ.get('BPB_MERGE_IDENTITY', '1') != '0'
         self.fold_eval_bn = os.environ.get('BPB_FOLD_EVAL_BN', '1') != '0'
         self.dgrad_bn_partials = os.environ.get('BPB_DGRAD_BN', '1') != '0'    # BatchNorm-backward partials from the dgrad epilogue
+        self.use_s1w = os.environ.get('BPB_CONV_S1W', '1') != '0'              # 0: strided 3x3 data gradients on the general kernel
         self.eval_residual_epilogue = os.environ.get('BPB_EVAL_RES', '1') != '0'   # eval plan: residual adds in the conv epilogue
         self.bn_momentum = BN_MOMENTUM     # running-statistics momentum of every BatchNorm of this plan
         # weight-gradient launches (+ their slab reduces) of the backward plan on a second stream (csrc/plan.cpp: bpb_plan_run2)
@@ -422,6 +423,52 @@ class Net:
             p.stats = st_buf.data_ptr()
             stats.append(st_buf)
         self.debug_convs.append((p, x_buf, w_packed, y_buf))
+        return p
+
+    def s1w_problem(self, dy_buf, dy_dims, w_packed, dx_buf, dx_hw, ph, pw, cin, cout, accumulate, ck=None, probe=False):
+        """One parity class (ph, pw) of the data gradient of a stride-2 3x3 pad-1 convolution as a ConvS1wProb (csrc/conv_s1w.hip):
+        dx[n][2a + ph][2b + pw] (+)= sum_{u, v} dy[n][a + u][b + v] . W[ph + 1 - 2u][pw + 1 - 2v]^T; `cin` = channels of dy (the
+        convolution's output channels), `cout` = channels of dx.  None if the class does not fit the kernel (tiny maps)."""
+        n, hi, wi = dy_dims
+        h, w = dx_hw
+        a, b = (h - ph + 1) // 2, (w - pw + 1) // 2
+        if a < 1 or b < 1 or (hi, wi) != ((h - 1) // 2 + 1, (w - 1) // 2 + 1):
+            return None
+        rh, rw = 1 + ph, 1 + pw
+        ti, th, tw = choose_tile(n, a, b, 128)
+        hh, hw = th + rh - 1, tw + rw - 1
+        cks = [c_ for c_ in (16, 8) if cin % c_ == 0] if ck is None else [ck]
+        forced = getattr(self, 'force_ck', None)
+        if forced and cin % forced == 0 and ck is None:
+            cks = [forced]
+        ck = None
+        for c_ in cks:
+            slots = ti * hh * hw * ((c_ + 4) // 4)
+            lds = 2 * ((slots + 3) // 4 * 4 + rh * rw * (c_ // 4) * 32) * 16
+            if (slots + 255) // 256 <= 8 and lds <= 160 * 1024 // 4:       # four workgroups per CU
+                ck = c_
+                break
+        if ck is None:
+            return None
+        p = ConvS1wProb()
+        p.x, p.w, p.y = dy_buf.data_ptr(), w_packed.data_ptr(), dx_buf.data_ptr()
+        p.N, p.H, p.W, p.Cin, p.Cout, p.Hi, p.Wi = n, h, w, cin, cout, hi, wi
+        p.A, p.B, p.ooh, p.oow, p.RH, p.RW = a, b, ph, pw, rh, rw
+        for u in range(rh):
+            for v in range(rw):
+                p.wt[u * rw + v] = (ph + 1 - 2 * u) * 3 + (pw + 1 - 2 * v)
+        p.lTI, p.lTH, p.lTW = _log2(ti), _log2(th), _log2(tw)
+        p.HH, p.HW, p.CK, p.LD = hh, hw, ck, ck + 4
+        p.tiles_a, p.tiles_b = _cdiv(a, th), _cdiv(b, tw)
+        p.n_mtiles = _cdiv(n, ti) * p.tiles_a * p.tiles_b
+        p.n_ntiles = _cdiv(cout, 32)
+        p.blk_begin, p.accumulate = 0, accumulate
+        p.xr = 1 if os.environ.get('BPB_XCD_MAP', '1') != '0' else 0
+        p.x_bytes, p.w_bytes, p.y_bytes = dy_buf.numel() * 4, w_packed.numel() * 4, dx_buf.numel() * 4
+        p.magic_spp, p.magic_hw, p.magic_hh = magic(p.LD // 4), magic(hw), magic(hh)
+        p.magic_nt, p.magic_tb, p.magic_ta = magic(p.n_ntiles), magic(p.tiles_b), magic(p.tiles_a)
+        if not probe:
+            self.debug_convs.append((p, dy_buf, w_packed, dx_buf))
         return p
 
     def conv_problem(self, x_buf, x_dims, w_packed, y_buf, y_dims, a, b, out_map, sa, origin, taps, cin, cout,
@@ -1301,6 +1348,20 @@ class Net:
                     x.last_s1_dgrad = (rec, prob, self._bwd_region, bwd.slot)
                 return
         st, pad = cv.stride, cv.pad
+        if self.use_s1 and self.use_s1w and st == 2 and r == 3 and s == 3 and pad == 1 and cout % 8 == 0 and x.C % 4 == 0:
+            # (one channel chunk for the four classes -- they share a launch: the one the 2x2 window fits with)
+            big = self.s1w_problem(gy, (y.N, y.H, y.W), cv.wd, gx, (x.H, x.W), 1, 1, cout, x.C, acc, probe=True)
+            probs = [self.s1w_problem(gy, (y.N, y.H, y.W), cv.wd, gx, (x.H, x.W), ph, pw, cout, x.C, acc, ck=big.CK)
+                     for ph in (0, 1) for pw in (0, 1)] if big is not None else [None]
+            if all(p_ is not None for p_ in probs):
+                for prob in probs:
+                    npix = prob.N * prob.A * prob.B
+                    rec = Rec(nv.OP_CONV_S1W, 'conv_dgrad bpb_conv_s1w_kernel<%d>' % (prob.CK // 8), 2.0 * npix * prob.RH * prob.RW * prob.Cin * prob.Cout,
+                              4.0 * (npix * prob.Cout + prob.N * prob.Hi * prob.Wi * prob.Cin / 4.0), desc=prob, key=('s1w', prob.CK),
+                              blocks=prob.n_mtiles * prob.n_ntiles, work=prob.RH * prob.RW * prob.Cin)
+                    rec.together = id(cv)          # the parity classes write disjoint pixels of dx: one grouped launch
+                    bwd.add(rec)
+                return
         for ph in range(st):
             for pw in range(st):
                 a = -(-(x.H - ph) // st)

@@ -141,6 +141,32 @@ typedef struct BpbConvS1Prob {
     int tstore;             // 1: epilogue through an LDS transpose, 16-byte stores (plain forward problems of single-tile waves)
 } BpbConvS1Prob;
 
+/* One parity class of the data gradient of a STRIDE-2 3x3 convolution on the lean kernel family (csrc/conv_s1w.hip):
+ *   dx[n][2a + ph][2b + pw][:] (+)= sum_{u < RH, v < RW} dy[n][a + u][b + v][:] . W_{wt[u * RW + v]}
+ * -- the input pixels of one row / column parity see a 1- or 2-tap window of dy (hrnet.py:240-250, :459-481, the stem :319-323 and
+ * resnet.py:31-49 strided 3x3 convolutions, backward).  The four classes of a convolution (windows 1x1, 1x2, 2x1, 2x2) share
+ * one grouped launch.  x = dy, Cin = the convolution's output channels, Cout = its input channels. */
+typedef struct BpbConvS1wProb {
+    const float* x;         // dy [N][Hi][Wi][Cin]
+    const float* w;         // packed [tap][Cin/4][Cout][4] (the data-gradient packing of bpb_pack_weights)
+    float* y;               // dx [N][H][W][Cout]
+    int N, H, W, Cin, Cout; // Cin multiple of 8, Cout multiple of 4
+    int Hi, Wi;             // extent of dy
+    int A, B;               // class domain: output pixel (a, b) -> (a * 2 + ooh, b * 2 + oow), a < A, b < B
+    int ooh, oow;
+    int RH, RW;             // window: 1 or 2 rows / columns of dy starting at (a, b); rows / columns beyond dy read zero
+    int wt[4];              // packed-weight tap of window element u * RW + v
+    int lTI, lTH, lTW;      // M tile = 2^lTI images x 2^lTH x 2^lTW class pixels = 128
+    int HH, HW;             // staged extent of a tile: TH + RH - 1, TW + RW - 1
+    int CK, LD;             // channel chunk (8, 16, 32) and LDS pitch of a staged pixel (CK + 4 floats)
+    int tiles_a, tiles_b, n_mtiles, n_ntiles;
+    int blk_begin;
+    int accumulate;         // dx += result
+    int xr;                 // XCD-aware block -> tile map
+    unsigned x_bytes, w_bytes, y_bytes;
+    unsigned magic_spp, magic_hw, magic_hh, magic_nt, magic_tb, magic_ta;
+} BpbConvS1wProb;
+
 /* weight-gradient problem: dW[t][ci][co] = sum_{n,a,b} x[n, a*sa + t/S + ih0, b*sa + t%S + iw0, ci] * dy[n,a,b,co] */
 typedef struct BpbWgradProb {
     const float* x;        // NHWC input of the conv
@@ -334,6 +360,7 @@ typedef enum BpbOpKind {
     BPB_OP_BILINEAR_MULTI_FWD = 28, /* p0 device BpbBilinearArgs[], p1 host copy, p2 stats partials or null, i0 n, i1 blocks */
     BPB_OP_BILINEAR_MULTI_BWD = 29, /* p0 device BpbBilinearBwdDesc[], p1 host copy, i0 n */
     BPB_OP_WGRAD1X1 = 30,          /* p0 device BpbWgrad1x1Prob[], p1 host copy, i0 nprobs */
+    BPB_OP_CONV_S1W = 31,          /* p0 device BpbConvS1wProb[], p1 host copy, i0 nprobs */
 } BpbOpKind;
 
 // generic op record; slot meaning per kind is documented next to each case; i[10] = stream slot (0 = the caller's stream, 1..3 = branch streams,
@@ -368,6 +395,9 @@ int bpb_wgrad_reduce_multi(const BpbWgradReduceDesc* d_descs, const BpbWgradRedu
                            hipStream_t stream);
 int bpb_conv_s1_init(void);
 int bpb_conv_s1(const BpbConvS1Prob* d_probs, const BpbConvS1Prob* h_probs, int nprobs, hipStream_t stream);
+/* parity classes of strided 3x3 data gradients (conv backward-input of hrnet.py:240-250 / resnet.py:31-49 stride-2 convolutions) */
+int bpb_conv_s1w_init(void);
+int bpb_conv_s1w(const BpbConvS1wProb* d_probs, const BpbConvS1wProb* h_probs, int nprobs, hipStream_t stream);
 int bpb_conv_wgrad(const BpbWgradProb* d_probs, const BpbWgradProb* h_probs, int nprobs, hipStream_t stream);
 int bpb_wgrad_reduce(const float* ws, float* dw, int nsplit, int T, int Cin, int Cin_real, int Cout, int accumulate,
                      hipStream_t stream);

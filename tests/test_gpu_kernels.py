@@ -930,3 +930,48 @@ def test_masked_maxpool_head_against_autograd(shape):
     dx2 = before.clone()
     nv.call('bpb_masked_maxpool_bwd_dx', Gd.data_ptr(), pmd.data_ptr(), arg.data_ptr(), dx2.data_ptr(), n, hw, c, j, nv.stream())
     assert torch.equal(dx, dx2), 'fixed summation order: repeated launches are bit-identical'
+
+
+@pytest.mark.parametrize('ck', [None, 8, 16])
+@pytest.mark.parametrize('case', [(4, 32, 16, 64, 64), (3, 33, 17, 32, 128), (2, 24, 8, 48, 96), (5, 9, 6, 16, 8), (8, 16, 8, 128, 256)])
+def test_strided_data_gradient_as_windowed_parity_classes(case, ck):
+    """Data gradient of stride-2 3x3 convolutions on csrc/conv_s1w.hip: four parity classes (1x1 ... 2x2 windows of dy) in one
+    launch, even and odd extents, every channel chunk; a tensor read by TWO strided convolutions takes the second gradient in
+    the accumulate mode.  Against conv backward-input of PyTorch in fp64 (hrnet.py:240-250 / resnet.py:31-49, backward)."""
+    n, h, w, cin, cout = case
+    g = torch.Generator().manual_seed(77 + sum(case))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wts = [torch.randn(c_, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5 for c_ in (cout, 2 * cout)]
+    net = Net(DEV)
+    net.force_ck = ck
+    xa = Act(net, n, h, w, cin)
+    xa.buf.copy_(nhwc(x))
+    nodes, params = [], []
+    for wt in wts:
+        wp = wt.to(DEV)
+        wp.grad = torch.zeros_like(wp)
+        params.append(wp)
+        nodes.append(net.conv(xa, wp, 2, 1))
+    net.finalize(train_backward=True)
+    dprobs = [d[0] for d in net.debug_convs if isinstance(d[0], nv.ConvS1wProb)]
+    assert len(dprobs) == 8 and sorted((d.RH, d.RW) for d in dprobs) == sorted([(1, 1), (1, 2), (2, 1), (2, 2)] * 2)
+    assert sorted(d.accumulate for d in dprobs) == [0] * 4 + [1] * 4
+    if ck is not None and (2 * cout) % ck == 0 and cout % ck == 0:
+        assert all(d.CK == ck for d in dprobs)
+    net.run(net.plan_train)
+    grs = []
+    for nd in nodes:
+        gr = torch.randn(nd.y.buf.shape, generator=g)
+        nd.y.grad.copy_(gr)
+        grs.append(gr)
+    xa.grad.fill_(float('nan'))               # every element must be written by the first (non-accumulating) gradient
+    net.run(net.plan_bwd)
+    torch.cuda.synchronize()
+    xr = x.double().requires_grad_(True)
+    tot = sum((F.conv2d(xr, wt.double(), stride=2, padding=1) * nchw(gr).double()).sum() for wt, gr in zip(wts, grs))
+    tot.backward()
+    assert rel_err(nchw(xa.grad), xr.grad) < 2e-5, 'strided dgrad'
+    first = xa.grad.clone()
+    net.run(net.plan_bwd)
+    torch.cuda.synchronize()
+    assert torch.equal(first, xa.grad), 'repeated launches are bit-identical'

@@ -44,7 +44,7 @@ def test_ctypes_mirrors_have_the_c_layout(tmp_path):
     import subprocess
     if shutil.which('gcc') is None:
         pytest.skip('no C compiler')
-    pairs = {'BpbConvProb': nv.ConvProb, 'BpbConvS1Prob': nv.ConvS1Prob, 'BpbS1BnBwd': nv.S1BnBwd, 'BpbBnFinDesc': nv.BnFinDesc, 'BpbBnBwdFinDesc': nv.BnBwdFinDesc,
+    pairs = {'BpbConvProb': nv.ConvProb, 'BpbConvS1Prob': nv.ConvS1Prob, 'BpbConvS1wProb': nv.ConvS1wProb, 'BpbS1BnBwd': nv.S1BnBwd, 'BpbBnFinDesc': nv.BnFinDesc, 'BpbBnBwdFinDesc': nv.BnBwdFinDesc,
              'BpbWgradReduceDesc': nv.WgradReduceDesc, 'BpbWgradProb': nv.WgradProb, 'BpbPackProb': nv.PackProb, 'BpbFuseArgs': nv.FuseArgs,
              'BpbTermBwdArgs': nv.TermBwdArgs, 'BpbBilinearArgs': nv.BilinearArgs, 'BpbBilinearBwdDesc': nv.BilinearBwdDesc, 'BpbWgrad1x1Prob': nv.Wgrad1x1Prob, 'BpbGemmProb': nv.GemmProb, 'BpbBnFinalizeArgs': nv.BnFinalizeArgs,
              'BpbBnEvalDesc': nv.BnEvalDesc, 'BpbPlanOp': nv.PlanOp, 'BpbHeadBranch': nv.HeadBranch, 'BpbS1Split': nv.S1Split}
@@ -171,7 +171,8 @@ def test_conv_descriptors_forward_dgrad_wgrad(case):
     x_nhwc = np.zeros((n, h, w, cpad))
     x_nhwc[..., :cin] = xin.permute(0, 2, 3, 1).numpy()
     prob = net.debug_convs[0][0]
-    run = lambda pr, *a: (emu.run_conv_s1 if isinstance(pr, nv.ConvS1Prob) else emu.run_conv)(pr, *a)
+    run = lambda pr, *a: (emu.run_conv_s1 if isinstance(pr, nv.ConvS1Prob) else emu.run_conv_s1w if isinstance(pr, nv.ConvS1wProb)
+                          else emu.run_conv)(pr, *a)
     assert isinstance(prob, nv.ConvS1Prob) == (stride in (1, 2) and k in (1, 3) and pad == k // 2 and cin % 8 == 0 and cout % 8 == 0)
     y = np.zeros((n, node.y.H, node.y.W, cout))
     stats = run(prob, x_nhwc, emu.pack_fwd(wt.numpy(), cpad), y)
@@ -187,6 +188,11 @@ def test_conv_descriptors_forward_dgrad_wgrad(case):
         gx = np.full((n, h, w, cin), np.nan)
         dprobs = [d[0] for d in net.debug_convs[1:]]
         assert len(dprobs) >= 1
+        # stride-2 3x3 data gradients: four windowed parity classes on the lean kernel family (csrc/conv_s1w.hip)
+        assert all(isinstance(d, nv.ConvS1wProb) for d in dprobs) == (stride == 2 and k == 3 and pad == 1 and cout % 8 == 0 and cin % 4 == 0)
+        if isinstance(dprobs[0], nv.ConvS1wProb):
+            assert sorted((d.RH, d.RW) for d in dprobs) == [(1, 1), (1, 2), (2, 1), (2, 2)]
+            assert len({g_.key for g_ in net.bwd if g_.kind == nv.OP_CONV_S1W}) == 1, 'the four classes share one launch'
         first = True
         for dp in dprobs:
             assert dp.accumulate == 0      # single consumer in this mini graph
