@@ -190,7 +190,10 @@ __device__ __forceinline__ void s1w_tile(const BpbConvS1wProb& P, int bid, float
         for (int r = 0; r < 16; ++r) acc[r] += old[r];
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[r]), ry, (int)offs[r], 0, 0);
+    for (int r = 0; r < 16; ++r) {
+        const float v = acc[r];      // (a scalar copy: __builtin_bit_cast applied to the vector ELEMENT expression reads element 0 for every r)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, (int)offs[r], 0, 0);
+    }
 }
 
 template <int KG>

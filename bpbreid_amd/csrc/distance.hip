@@ -241,15 +241,11 @@ __global__ __launch_bounds__(512, 2) void bpb_part_distance_tiled_kernel(const f
         mma(a[1], b[1]);
         if (++ch == nch) {                                  // ---- this part is complete: distances, mask, fold
             __syncthreads();                                // the norms staged at the part's first chunk (nch may be 1)
-            // per-part base of the output block of this tile: the lane offsets below stay 32-bit
+            // per-part base of the output block of this tile: the lane offsets below stay 32-bit.  (Round 4 measured the per-part block
+            // through an LDS transpose -- 8 sixteen-byte stores per lane and part instead of 32 four-byte ones: 4.86 -> 4.92 ms, no gain.
+            // The 0.9 ms the [P,Q,G] output costs is not store issue: stores count in vmcnt on gfx950, so the barrier that waits for the
+            // next chunk's DMA also waits for the part's 1.47 GB / P store burst.  Removed.)
             float* pbase = parts_out ? parts_out + ((long)p * Q + q0) * G : nullptr;
-            // Round 4: the [P,Q,G] block goes out through an LDS transpose.  In the MFMA layout a lane owns ONE gallery column of 16
-            // query rows: 32 four-byte stores per lane and part, and the store issue (not the bytes: 300 GB/s) is what the 0.85 ms
-            // between the kernel with and without the per-part matrix pays for.  Each wave writes its 32 x 32 sub-tile into ITS
-            // 4.5 KiB of the staging buffer this part's last chunk just released (every wave is past the barrier above; the next DMA
-            // into that buffer is issued behind the next barrier) and reads it back as [row][4 columns]: 8 sixteen-byte stores.
-            const bool tstore = pbase != nullptr && (G & 3) == 0;
-            float* ttile = (float*)((char*)smem + (w & 1) * BUF) + wave * (32 * 36);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const int g = gcol[nt];
@@ -281,22 +277,11 @@ __global__ __launch_bounds__(512, 2) void bpb_part_distance_tiled_kernel(const f
                             else if (mode == 2) m = sqrtf(qvis[(long)(q0 + row) * P + p] * gv);
                             float pv = d;
                             if (mode == 1 && m == 0.f) pv = -1.f;
-                            if (tstore) ttile[(row - wq * 32) * 36 + l31] = pv;
-                            else if (pbase) pbase[(unsigned)row * (unsigned)G + (unsigned)g] = pv;
+                            if (pbase) pbase[(unsigned)row * (unsigned)G + (unsigned)g] = pv;
                             if (pv > lmax) lmax = pv;
                             if (STRAT == 1) { if (m != 0.f && d > comb[nt][r]) comb[nt][r] = d; }
                             else comb[nt][r] += d * m;
                         }
-                    }
-                }
-                if (tstore) {
-                    const int trow = lane >> 3, cq = lane & 7;
-                    const int gq = g0 + wg * 64 + nt * 32 + cq * 4;              // first of this lane's four gallery columns
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int row = wq * 32 + trow + 8 * i;
-                        const f32x4 v = *(const f32x4*)(ttile + (trow + 8 * i) * 36 + cq * 4);
-                        if (q0 + row < Q && gq < G) *(f32x4*)(pbase + (unsigned)row * (unsigned)G + (unsigned)gq) = v;   // (G % 4 == 0: whole quads)
                     }
                 }
             }

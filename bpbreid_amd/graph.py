@@ -34,6 +34,18 @@ OP_ALIGN = -2                # merge marker: a chain waits here until every chai
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 MAX_GROUP = 16          # problems per grouped launch (kernel-side limit)
+# Tile / split constants that the sweeps of rounds 1-3 settled (tools/wgrad_sweep.py, profiles/r02_s1_sweep.txt, r02_wgrad_sweep.txt);
+# the measurement tools change them here, they are not environment switches any more.
+TUNE = {
+    's1_lds_kb': 53,             # LDS budget of a conv_s1 workgroup that still leaves three workgroups per CU
+    'wgrad_tpb': 2,              # first-generation weight gradient: pixel tiles per workgroup / workgroups per launch / co sub-tiles
+    'wgrad_blocks': 512,
+    'wgrad_ntw_max': 2,
+    'wgrad16_blocks': 256,       # wgrad16: workgroups per problem (64 ... 384 measured: 47.1, 45.3, 42.6, 41.9, 40.2, 42.0 ms per step)
+    'wgrad16_tpb': 4,
+    'wgrad1x1_blocks': 512,
+    'concat_blocks': 2048,       # head concatenation: 8 workgroups per CU
+}
 
 
 def _pow2ceil(x):
@@ -312,16 +324,14 @@ class Net:
         k2 = t * cin // 2                                  # MFMAs per 32x32 wave tile
         # wave tile (mt x 32 pixels) x (nt x 32 channels): enough MFMAs per workgroup to amortise its prologue / epilogue
         # (~600 instructions), few enough that the deep low-resolution branches still split into many workgroups
-        target = int(os.environ.get('BPB_S1_TARGET', '320'))
         cands = [(1, 1), (2, 1), (1, 2), (2, 2)]
         cands = [c_ for c_ in cands if c_[1] * 32 <= max(32, _pow2ceil(cout))]
         forced = getattr(self, 'force_tile', None)         # tests pin (mt, lwn, nt) to cover every kernel variant
-        policy = os.environ.get('BPB_S1_POLICY', 'auto')
         if forced is not None:
             mt_r, lwn, nt = forced
             if (nt * 32) << lwn > max(32, _pow2ceil(cout)):
                 nt, lwn = 1, 0
-        elif policy == 'auto':
+        else:
             # measured on MI355X (tools/s1_sweep.py, profiles/r02_s1_sweep.txt).  Inside a fork region the branch convolutions
             # share ONE grouped launch only if they use the same kernel variant: 3x3 -> 32-pixel x 32-channel wave tiles, 128 x 32
             # workgroup tiles (with 8-channel chunks three workgroups fit a CU: the four-branch module step runs at 104 TFLOP/s
@@ -347,18 +357,6 @@ class Net:
                 lwn = 1 if cout >= 128 else 0
                 if k2 >= 256 and cout >= 1024 and wgs(2, nt, lwn) >= 512:
                     mt_r = 2
-        else:
-            if policy == 'u11':
-                mt_r, nt = 1, 1
-            elif policy == 'u21':
-                mt_r, nt = 2, 1
-            else:
-                mt_r, nt = cands[0]
-                for c_ in cands:                            # smallest tile that reaches the target; else the largest
-                    mt_r, nt = c_
-                    if k2 * c_[0] * c_[1] >= target:
-                        break
-            lwn = 1 if cout >= 64 * nt and os.environ.get('BPB_S1_LWN', '1') != '0' else 0
         pad256 = lambda v_: (v_ + 255) // 256 * 256
         cks = [c_ for c_ in (32, 16, 8) if cin % c_ == 0]
         assert cks, 'conv_s1: Cin must be a multiple of 8'
@@ -376,7 +374,7 @@ class Net:
                 halo, wts = pad256(halo_slots), pad256(w_slots)          # DMA pieces of 256 x 16 B
                 return halo, wts, max(8192, 2 * ((halo_slots + 3) // 4 * 4 + w_slots) * 16)     # LDS: regions packed, two buffers
             ok = [c_ for c_ in cks if sizes(c_)[0] <= 12 * 256 and sizes(c_)[1] <= 12 * 256]   # <= 12 DMA pieces per thread
-            for limit_kb in (int(os.environ.get('BPB_S1_LDS_KB', '53')), 53, 79, 160):    # >= 3, 3, 2, 1 workgroups per CU
+            for limit_kb in (TUNE['s1_lds_kb'], 53, 79, 160):    # >= 3, 3, 2, 1 workgroups per CU
                 fit = [c_ for c_ in ok if sizes(c_)[2] <= limit_kb * 1024]
                 if fit:
                     ck = fit[0]
@@ -760,7 +758,7 @@ class Net:
                         host[q] = self._bilinear_args(a.buf, out.buf, a, out, cc)
                         cc += a.C
                     dev = self._dev_struct(host)
-                    nblk = max(1, min(int(os.environ.get('BPB_CONCAT_BLOCKS', '2048')), out.N * out.H * out.W // 16))      # 8 workgroups per CU
+                    nblk = max(1, min(TUNE['concat_blocks'], out.N * out.H * out.W // 16))      # 8 workgroups per CU
                     out.stats_partials = torch.empty(nblk * 2 * out.C, device=self.device, dtype=torch.float64)
                     out.stats_nblocks = nblk
                     byt = 4.0 * (sum(a.buf.numel() for a in srcs) + out.buf.numel())
@@ -1225,15 +1223,14 @@ class Net:
         wp.n_mtiles = (-(-x.N // ti)) * wp.tiles_a * wp.tiles_b
         # 1x1: two 32-channel sub-tiles per workgroup.  Four (a 64 KB dy tile, 86 KB of LDS -> one workgroup per CU, no
         # double buffer) measured 2.4x slower: 19 vs 45 TFLOP/s on the same FLOPs (64->256 vs 256->64 @64x32).
-        ntw_max = int(os.environ.get('BPB_WGRAD_NTW_MAX', '2'))
+        ntw_max = TUNE['wgrad_ntw_max']
         ntw = min(ntw_max, 4 if cout >= 128 else 2 if cout >= 64 else 1) if t == 1 else 1
         wp.ntw = ntw
         wp.n_citiles = -(-x.C // 32)
         wp.n_cotiles = -(-cout // (32 * ntw))
         wp.n_tapgroups = 1 if t == 1 else -(-t // 9)
         pairs = wp.n_citiles * wp.n_cotiles * wp.n_tapgroups
-        tpb_w = int(os.environ.get('BPB_WGRAD_TPB', '2'))          # tuning knobs (A/B measurements)
-        blk_w = int(os.environ.get('BPB_WGRAD_BLOCKS', '512'))
+        tpb_w, blk_w = TUNE['wgrad_tpb'], TUNE['wgrad_blocks']
         wp.nsplit = max(1, min(-(-wp.n_mtiles // tpb_w), -(-blk_w // pairs)))
         wp.blk_begin = 0
         wp.magic_hw, wp.magic_hh = magic(wp.HW), magic(wp.HH)
@@ -1242,9 +1239,7 @@ class Net:
         assert lds1 <= 160 * 1024, 'wgrad tile exceeds LDS'
         # measured on MI355X: the DMA double buffer pays for 1x1 filters (small tiles, 2 workgroups/CU still fit) and loses
         # for 3x3 ones, where two halo images leave one workgroup per CU (65 us vs 53 us on 32->32 @ 64x32, N=64)
-        wp.dma = 1 if (getattr(self, 'use_dma', True) and ((t == 1 and os.environ.get('BPB_WGRAD_DMA1', '1') != '0') or
-                                                          (t > 1 and os.environ.get('BPB_WGRAD_DMA3') == '1'))
-                       and 2 * lds1 <= 160 * 1024) else 0
+        wp.dma = 1 if (getattr(self, 'use_dma', True) and t == 1 and 2 * lds1 <= 160 * 1024) else 0
         wp.x_bytes, wp.dy_bytes = x.buf.numel() * 4, gy.numel() * 4
         wp.magic_spp = magic(wp.LD // 4)
         elems = wp.nsplit * t * x.C * cout
@@ -1268,8 +1263,7 @@ class Net:
             wp.tiles_a, wp.tiles_b = _cdiv(y.H, th), _cdiv(y.W, tw)
             wp.n_mtiles = _cdiv(x.N, ti) * wp.tiles_a * wp.tiles_b
             wp.magic_hw, wp.magic_hh = magic(wp.HW), magic(wp.HH)
-            blk16 = int(os.environ.get('BPB_WGRAD16_BLOCKS', '256'))
-            tpb16 = int(os.environ.get('BPB_WGRAD16_TPB', '4'))
+            blk16, tpb16 = TUNE['wgrad16_blocks'], TUNE['wgrad16_tpb']
             wp.nsplit = max(1, min(_cdiv(wp.n_mtiles, tpb16), _cdiv(blk16, pairs)))
             wp.xr = 1 if os.environ.get('BPB_XCD_MAP', '1') != '0' else 0
             elems = wp.nsplit * t * x.C * cout
@@ -1290,7 +1284,7 @@ class Net:
             w1.x, w1.dy = x.buf.data_ptr(), gy.data_ptr()
             w1.npix, w1.Cin, w1.Cout, w1.lwm = npix, x.C, cout, lwm
             w1.n_citiles, w1.n_cotiles, w1.n_ptiles = nci, nco, _cdiv(npix, 32)
-            blk1 = int(os.environ.get('BPB_WGRAD1X1_BLOCKS', '512'))
+            blk1 = TUNE['wgrad1x1_blocks']
             w1.nsplit = max(1, min(_cdiv(w1.n_ptiles, 8), _cdiv(blk1, nci * nco)))
             w1.x_bytes, w1.dy_bytes = x.buf.numel() * 4, gy.numel() * 4
             w1.sa, w1.Hi, w1.Wi, w1.A, w1.B = cv.stride, x.H, x.W, y.H, y.W
@@ -1401,9 +1395,8 @@ class Net:
 
     def _side_objects(self):
         if self._side is None:
-            prio = int(os.environ.get('BPB_SIDE_PRIO', '0'))
-            with torch.cuda.device(self.device):
-                side = torch.cuda.Stream(device=self.device, priority=prio)
+            with torch.cuda.device(self.device):       # (same priority as the caller's stream: a high-priority side stream measured the same)
+                side = torch.cuda.Stream(device=self.device)
             evs = []
             for _ in range(2):
                 h = C.c_void_p()
