@@ -440,11 +440,14 @@ class Net:
         if forced and cin % forced == 0 and ck is None:
             cks = [forced]
         ck = None
-        for c_ in cks:
-            slots = ti * hh * hw * ((c_ + 4) // 4)
-            lds = 2 * ((slots + 3) // 4 * 4 + rh * rw * (c_ // 4) * 32) * 16
-            if (slots + 255) // 256 <= 8 and lds <= 160 * 1024 // 4:       # four workgroups per CU
-                ck = c_
+        for limit in (160 * 1024 // 4, 160 * 1024 // 2, 160 * 1024):       # four, two, one workgroup(s) per CU
+            for c_ in cks:
+                slots = ti * hh * hw * ((c_ + 4) // 4)
+                lds = 2 * ((slots + 3) // 4 * 4 + rh * rw * (c_ // 4) * 32) * 16
+                if (slots + 255) // 256 <= 8 and lds <= limit:
+                    ck = c_
+                    break
+            if ck is not None:
                 break
         if ck is None:
             return None

@@ -954,8 +954,10 @@ def test_strided_data_gradient_as_windowed_parity_classes(case, ck):
         nodes.append(net.conv(xa, wp, 2, 1))
     net.finalize(train_backward=True)
     dprobs = [d[0] for d in net.debug_convs if isinstance(d[0], nv.ConvS1wProb)]
-    assert len(dprobs) == 8 and sorted((d.RH, d.RW) for d in dprobs) == sorted([(1, 1), (1, 2), (2, 1), (2, 2)] * 2)
-    assert sorted(d.accumulate for d in dprobs) == [0] * 4 + [1] * 4
+    # (a forced chunk whose staged tile does not fit the kernel's eight DMA pieces leaves that convolution on the general kernel)
+    assert len(dprobs) in ((8,) if ck is None else (0, 4, 8)) and sorted((d.RH, d.RW) for d in dprobs) == sorted([(1, 1), (1, 2), (2, 1), (2, 2)] * (len(dprobs) // 4))
+    if len(dprobs) == 8:
+        assert sorted(d.accumulate for d in dprobs) == [0] * 4 + [1] * 4
     if ck is not None and (2 * cout) % ck == 0 and cout % ck == 0:
         assert all(d.CK == ck for d in dprobs)
     net.run(net.plan_train)

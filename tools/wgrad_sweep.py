@@ -6,6 +6,7 @@ sys.path[:0] = [ROOT]
 import torch
 from bpbreid_amd import native as nv
 from bpbreid_amd.graph import Net, Act
+from bpbreid_amd import graph as G
 
 dev = torch.device('cuda', 0)
 nv.init_device()
@@ -14,8 +15,13 @@ SHAPES = [(64, 32, 32, 32), (32, 16, 64, 64), (16, 8, 128, 128), (8, 4, 256, 256
 
 
 def build(shapes, grouped, env):
+    # lower-case keys are entries of graph.TUNE (tile / split constants), upper-case ones environment switches
+    tune = {k: v for k, v in env.items() if k.islower()}
+    env = {k: v for k, v in env.items() if not k.islower()}
     old = {k: os.environ.get(k) for k in env}
+    old_tune = {k: G.TUNE[k] for k in tune}
     os.environ.update(env)
+    G.TUNE.update({k: int(v) for k, v in tune.items()})
     try:
         net = Net(dev)
         if grouped:
@@ -38,6 +44,7 @@ def build(shapes, grouped, env):
         net.finalize(True)
         return net
     finally:
+        G.TUNE.update(old_tune)
         for k, v in old.items():
             os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
 
@@ -57,9 +64,9 @@ def timed(net, prefix, reps=20):
     return s.elapsed_time(e) * 1e3 / reps
 
 
-CONFIGS = [('gen1', {'BPB_WGRAD16': '0'}), ('gen1 blk256', {'BPB_WGRAD16': '0', 'BPB_WGRAD_BLOCKS': '256'})]
+CONFIGS = [('gen1', {'BPB_WGRAD16': '0'}), ('gen1 blk256', {'BPB_WGRAD16': '0', 'wgrad_blocks': '256'})]
 for blk, tpb in itertools.product(('512', '256', '128', '64'), ('2', '4', '8')):
-    CONFIGS.append(('g2 blk%s tpb%s' % (blk, tpb), {'BPB_WGRAD16_BLOCKS': blk, 'BPB_WGRAD16_TPB': tpb}))
+    CONFIGS.append(('g2 blk%s tpb%s' % (blk, tpb), {'wgrad16_blocks': blk, 'wgrad16_tpb': tpb}))
 
 for group in [[s] for s in SHAPES] + [SHAPES[:4]]:
     flops = sum(2.0 * N * h * w * 9 * cin * cout for (h, w, cin, cout) in group)
