@@ -313,9 +313,19 @@ class Net:
         self.keep += [dev, st]
         return dev
 
+    def _region_slots(self):
+        """fork region -> number of branch chains recorded in it."""
+        if getattr(self, '_region_slots_cache', None) is None or self._region_slots_cache[0] != len(self.nodes):
+            slots = {}
+            for slot, region in zip(self.node_slots, self.node_regions):
+                if region:
+                    slots.setdefault(region, set()).add(slot)
+            self._region_slots_cache = (len(self.nodes), {r_: len(v_) for r_, v_ in slots.items()})
+        return self._region_slots_cache[1]
+
     # ---- tile / chunk selection ---------------------------------------------------------------------------------
     def s1_problem(self, x_buf, x_dims, w_packed, y_buf, cin, cout, r, bias=None, stats=None, accumulate=0, wflip=0, relu=0,
-                   in_region=True, stride=1):
+                   in_region=True, stride=1, nbranch=0):
         """Fill one ConvS1Prob (csrc/conv_s1.hip): y[N,H,W,cout] = conv_rxr(x[N,Hi,Wi,cin]), padding r // 2, stride 1 or 2;
         x_dims = (N, Hi, Wi)."""
         n, hi, wi = x_dims
@@ -342,6 +352,11 @@ class Net:
                 return _cdiv(n, ti_) * _cdiv(h, th_) * _cdiv(w, tw_) * _cdiv(cout, (32 * nt_) << lwn_)
             if r == 3 and in_region:
                 mt_r, nt, lwn = 1, 1, 0
+                # A TWO-branch module step (HRNet stage 2: 32 channels at 64x32 + 64 channels at 32x16) is 1536 workgroups of 128
+                # pixels on 1024 slots -- one and a half generations, 83 TFLOP/s against 98 / 108 for the three- / four-branch steps
+                # (gpurun_out/r04d plan timing).  With 256-pixel tiles it is ONE generation of 768 workgroups on 768 slots.
+                if str(nbranch) in os.environ.get('BPB_S1_BIGTILE_BRANCHES', '2').split(',') and stride == 1 and wgs(2, 1, 0) >= 256:
+                    mt_r = 2
                 # (round 3's mixed-tile variant -- two pixel sub-tiles per wave for the shallow wide branches inside the same launch --
                 #  measured -6 % / -2 % / 0 % on the two- / three- / four-branch launches, profiles/r03_s1_mixed_first.txt: removed)
             elif r == 3:
@@ -665,7 +680,7 @@ class Net:
                 prob = None
                 if self.use_s1 and cv.is_s1_fwd and (cv.stride == 1 or os.environ.get('BPB_S1_STRIDE2', '1') != '0'):
                     prob = self.s1_problem(x.buf, (x.N, x.H, x.W), cv.wf, y.buf, x.C, y.C, cv.R, bias=cv.bias, stats=stats,
-                                           in_region=region != 0, stride=cv.stride)
+                                           in_region=region != 0, stride=cv.stride, nbranch=self._region_slots().get(region, 0))
                 if prob is None:
                     prob = self.conv_problem(x.buf, (x.N, x.H, x.W), cv.wf, y.buf, (y.H, y.W), y.H, y.W, (1, 1, 0, 0),
                                              cv.stride, (-cv.pad, -cv.pad), (cv.R, cv.S, 0, 1, 0, 1, 0, cv.S, 1), x.C, y.C,
@@ -1337,7 +1352,7 @@ class Net:
         if self.use_s1 and cv.is_s1:
             # stride-1 'same' convolution: dx = conv(dy, W^T mirrored) -- the same lean kernel with the dgrad packing
             prob = self.s1_problem(gy, (y.N, y.H, y.W), cv.wd, gx, cout, x.C, cv.R, accumulate=acc, wflip=1,
-                                   in_region=self._bwd_region != 0)
+                                   in_region=self._bwd_region != 0, nbranch=self._region_slots().get(self._bwd_region, 0))
             if prob is not None:
                 rec = self._conv_rec(prob, 'conv_dgrad')
                 bwd.add(rec)
