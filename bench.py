@@ -51,7 +51,7 @@ def parse():
                     help='1: replay the step from one hipGraph (8 instead of 21 ms of host work per step; with --gpus N the RCCL '
                          'all-reduce launches are captured with the step and the ranks AGREE on graph vs eager); 0: eager launches '
                          '(the weight gradients then run on a side stream: 30.8 instead of 32.8 ms per step on one GPU); -1 (default): '
-                         'eager, unless the slowest rank\'s host loop needs more than 85 %% of the step -- then the graph')
+                         'eager; on one GPU the graph if the host loop needs more than 85 %% of the step (N > 1 reports the fraction only)')
     ap.add_argument('--dist-backend', default='nccl', help="'nccl' (= RCCL over xGMI; the default) or 'gloo' (functional check of the "
                     "multi-process path when the ranks have to share one GPU)")
     ap.add_argument('--dump-plan-timing', default='', help='write the per-record isolated timings of the forward and backward '
@@ -434,7 +434,7 @@ def main():
     torch.cuda.synchronize()
     want_graph = args.graph == 1
     host_bound = None
-    if args.graph == -1 and (not multi or args.dist_backend == 'nccl'):
+    if args.graph == -1:
         # eager is the faster schedule while the host keeps up (two-stream backward); a host loop that needs > 85 % of the step on
         # ANY rank (few cores per rank) makes the job host-bound: all ranks then switch to the captured step together
         probe = 3
@@ -448,7 +448,9 @@ def main():
         if multi:
             dist.all_reduce(ratio, op=dist.ReduceOp.MAX)
         host_bound = float(ratio)
-        want_graph = host_bound > 0.85
+        # (N > 1: reported only.  A captured step that holds RCCL launches has run on ONE rank so far (tests, --force-dist); the
+        #  first multi-rank job must not depend on it -- ask for it with --graph 1)
+        want_graph = host_bound > 0.85 and not multi
     if want_graph and (not multi or args.dist_backend == 'nccl'):     # (RCCL collectives are captured with the step)
         replay, mode, why = eng.capture_step_agreed(data, warmup=1)
         if why:
