@@ -209,7 +209,7 @@ def cpu_baseline(args):
     return cpu_train_leg(args.backbone, args.parts, args.height, args.width, args.classes, args.cpu_batch or 16, warm, timed, args.batch)
 
 
-PMC_FILE = 'profiles/r03_pmc_hbm.json'
+PMC_FILE = 'profiles/r04_pmc_hbm.json'
 
 
 def pmc_traffic(sym):

@@ -1,18 +1,33 @@
 #!/bin/bash
-# round 3: regenerate every measurement file under profiles/r03_* from the current build
-cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03final; mkdir -p $O
+# regenerate the measurement files under profiles/<round>_* from the current build:  bash tools/profile_all.sh [r04]
+cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; P=${1:-r04}; O=$R/gpurun_out/${P}final; mkdir -p $O
 # HBM traffic counters first: bench.py quotes roofline.traffic only from a file stamped with THIS build's source hash
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  (cd /tmp && timeout 600 rocprofv3 --pmc $c -d /tmp/pmc_$c -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_$c.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --pmc $c -d /tmp/pmc_$c -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-forward-only --no-eval --graph 0 > $O/pmc_$c.log 2>&1)
 done
 python tools/pmc_hbm.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE $O/pmc_hbm.json | head -12
-cp $O/pmc_hbm.json profiles/r03_pmc_hbm.json
+cp $O/pmc_hbm.json profiles/${P}_pmc_hbm.json
 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -1 $O/bench_default.json | cut -c1-200
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --dump-plan-timing $O/plan_timing.json > $O/bench_20steps.json 2>/dev/null
-rm -rf /tmp/profk; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/profk -o r03 -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $O/prof_bench.json 2> $O/prof_bench.err)
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-eval --dump-plan-timing $O/plan_timing.json > $O/bench_20steps.json 2>/dev/null
+python tools/plan_summary.py $O/plan_timing.json > $O/plan_summary.txt
+rm -rf /tmp/profk; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/profk -o $P -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-forward-only --no-eval --graph 0 > $O/prof_bench.json 2> $O/prof_bench.err)
 DB=$(find /tmp/profk -name "*.db" | head -1); python tools/rocprof_summary.py $DB $O/bench_kernel_stats.csv | tail -1
-python tools/step_trace.py $DB $O/step_trace.txt; tail -2 $O/step_trace.txt
+python tools/step_trace.py $DB $O/step_trace.txt; tail -3 $O/step_trace.txt
+python tools/fwd_bench.py hrnet32 > $O/forward_only_hrnet32.json 2>/dev/null; tail -1 $O/forward_only_hrnet32.json | cut -c1-300
+BPB_FWD_SPATIAL=1 python tools/fwd_bench.py hrnet32 > $O/forward_only_hrnet32_with_map.json 2>/dev/null
+python tools/fwd_bench.py resnet50 > $O/forward_only_resnet50.json 2>/dev/null
+rm -rf /tmp/profe; (cd /tmp && BPB_FWD_MODES=eval timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/profe -o ${P}e -- python $R/tools/fwd_bench.py hrnet32 > /dev/null 2>&1)
+DB=$(find /tmp/profe -name "*.db" | head -1); python tools/rocprof_summary.py $DB $O/forward_eval_kernel_stats.csv | tail -1
+python tools/eval_bench.py > $O/eval_bench.json 2> $O/eval_bench.err; tail -1 $O/eval_bench.json | cut -c1-300
+python tools/conv_bench.py > $O/conv_shapes.txt 2>&1; tail -14 $O/conv_shapes.txt
+python bench.py --backbone resnet50 --steps 20 --warmup 5 --no-cpu-baseline --no-eval > $O/bench_resnet50.json 2>/dev/null; tail -1 $O/bench_resnet50.json | cut -c1-200
+python bench.py --backbone hrnet48 --parts 8 --height 384 --width 128 --steps 10 --warmup 3 --no-cpu-baseline --no-eval > $O/bench_hrnet48_k8_384.json 2>/dev/null; tail -1 $O/bench_hrnet48_k8_384.json | cut -c1-200
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --force-dist --steps 20 --warmup 5 --no-cpu-baseline --no-forward-only --no-eval > $O/rccl_one_rank_bench.json 2>/dev/null; tail -1 $O/rccl_one_rank_bench.json | cut -c1-120
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --force-dist --graph 1 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-forward-only --no-eval > $O/bench_force_dist_graph.json 2>/dev/null; tail -1 $O/bench_force_dist_graph.json | cut -c1-120
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-forward-only --no-eval --graph 1 > $O/bench_graph.json 2>/dev/null; tail -1 $O/bench_graph.json | cut -c1-120
+# the form the driver uses for --gpus 1, with two ranks on this one GPU (gloo): bench.py launches its own ranks
+timeout 600 python bench.py --gpus 2 --dist-backend gloo --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-forward-only --no-eval > $O/bench_selfspawn_2ranks_gloo.json 2> $O/bench_selfspawn.err; tail -1 $O/bench_selfspawn_2ranks_gloo.json | cut -c1-200
 A="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
 Bc="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAVES"
 probe() {
@@ -26,24 +41,6 @@ probe() {
   grep -v "^W2026\|rocprofv3\|amdgpu.ids" /tmp/pmc_${name}_A.log | tail -1
 }
 { echo "== conv_s1 3x3 64x32 32->32 batch 64"; probe s1_b0 "conv_s1" tools/conv_pmc.py 64 32 32 32 3 10
-  echo "== conv_s1 3x3 32x16 64->64"; probe s1_b1 "conv_s1" tools/conv_pmc.py 32 16 64 64 3 10
-  echo "== wgrad16 64x32 32->32"; probe w16_b0 "wgrad16" tools/wgrad_pmc.py 64 32 32 32 3 10
+  echo "== the four-branch module step (x4 grouped launch)"; probe s1_x4 "conv_s1" tools/conv_pmc.py x4 10
   echo "== part distance Q=2048 G=20000 P=9 D=512"; probe dist "part_distance_tiled" tools/dist_pmc.py 2048 20000 9 512 2 1; } > $O/pmc_sq.txt 2>&1
-python tools/fwd_bench.py hrnet32 > $O/forward_only_hrnet32.json 2>/dev/null; tail -1 $O/forward_only_hrnet32.json | cut -c1-300
-BPB_FWD_SPATIAL=1 python tools/fwd_bench.py hrnet32 > $O/forward_only_hrnet32_with_map.json 2>/dev/null
-python tools/fwd_bench.py resnet50 > $O/forward_only_resnet50.json 2>/dev/null
-rm -rf /tmp/profe; (cd /tmp && BPB_FWD_MODES=eval timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/profe -o r03e -- python $R/tools/fwd_bench.py hrnet32 > /dev/null 2>&1)
-DB=$(find /tmp/profe -name "*.db" | head -1); python tools/rocprof_summary.py $DB $O/forward_eval_kernel_stats.csv | tail -1
-python tools/eval_bench.py > $O/eval_bench.json 2> $O/eval_bench.err; tail -1 $O/eval_bench.json | cut -c1-300
-python tools/conv_bench.py > $O/conv_shapes.txt 2>&1; tail -14 $O/conv_shapes.txt
-python bench.py --backbone resnet50 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_resnet50.json 2>/dev/null; tail -1 $O/bench_resnet50.json | cut -c1-200
-python bench.py --backbone hrnet48 --parts 8 --height 384 --width 128 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_hrnet48_k8_384.json 2>/dev/null; tail -1 $O/bench_hrnet48_k8_384.json | cut -c1-200
-timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --force-dist --steps 20 --warmup 5 --no-cpu-baseline > $O/rccl_one_rank_bench.json 2>/dev/null; tail -1 $O/rccl_one_rank_bench.json | cut -c1-120
-timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --force-dist --graph 1 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $O/bench_force_dist_graph.json 2>/dev/null; tail -1 $O/bench_force_dist_graph.json | cut -c1-120
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --graph 1 > $O/bench_graph.json 2>/dev/null; tail -1 $O/bench_graph.json | cut -c1-120
-python tools/mfma_peak.py > $O/mfma_peak.txt 2>/dev/null; tail -4 $O/mfma_peak.txt
-{ for what in x4 x3 x2 b0; do echo "=== $what"; timeout 300 python tools/s1_trace.py $what 2>&1 | grep -v amdgpu.ids; done
-  echo "=== x4 without the K split"; BPB_S1_SPLIT_RATIO=0 timeout 300 python tools/s1_trace.py x4 2>&1 | grep -v amdgpu.ids
-  echo "=== x4 without the K split, padded halo everywhere (three workgroups per CU)"; BPB_S1_NOPAD=0 BPB_S1_SPLIT_RATIO=0 timeout 300 python tools/s1_trace.py x4 2>&1 | grep -v amdgpu.ids; } > $O/s1_trace.txt 2>&1
-{ for abl in 0 32 64 96; do for what in x4 x3; do echo "=== $what S1_ABL=$abl"; S1_ABL=$abl timeout 300 python tools/s1_trace.py $what 2>&1 | grep -v amdgpu.ids | head -9; done; done; } > $O/s1_ablation_launch.txt 2>&1
-grep -A1 "===" $O/s1_ablation_launch.txt | grep -v "^--" | cut -c1-160
+timeout 900 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; tail -2 $O/pytest_gpu.txt
