@@ -713,7 +713,7 @@ def test_rccl_call_sequence_on_one_rank_leaves_the_trajectory_unchanged():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     common = ['--gpus', '1', '--steps', '3', '--warmup', '0', '--backbone', 'hrnet_w8', '--batch', '16', '--height', '128', '--width', '64',
-              '--classes', '32', '--no-cpu-baseline', '--no-roofline']
+              '--classes', '32', '--no-cpu-baseline', '--no-roofline', '--graph', '0', '--no-forward-only', '--no-eval']
     env = dict(os.environ)
     for kk in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(kk, None)
