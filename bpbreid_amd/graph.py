@@ -438,27 +438,26 @@ class Net:
         self.debug_convs.append((p, x_buf, w_packed, y_buf))
         return p
 
-    def s1w_problem(self, dy_buf, dy_dims, w_packed, dx_buf, dx_hw, ph, pw, cin, cout, accumulate, ck=None, probe=False):
-        """One parity class (ph, pw) of the data gradient of a stride-2 3x3 pad-1 convolution as a ConvS1wProb (csrc/conv_s1w.hip):
-        dx[n][2a + ph][2b + pw] (+)= sum_{u, v} dy[n][a + u][b + v] . W[ph + 1 - 2u][pw + 1 - 2v]^T; `cin` = channels of dy (the
-        convolution's output channels), `cout` = channels of dx.  None if the class does not fit the kernel (tiny maps)."""
+    def s1w_problem(self, dy_buf, dy_dims, w_packed, dx_buf, dx_hw, cin, cout, accumulate):
+        """The data gradient of a stride-2 3x3 pad-1 convolution as ONE ConvS1wProb (csrc/conv_s1w.hip: a workgroup computes the four
+        input-pixel parity classes of its 128 class pixels from one staged tile of dy); `cin` = channels of dy (the convolution's
+        output channels), `cout` = channels of dx.  None if the problem does not fit the kernel (tiny maps)."""
         n, hi, wi = dy_dims
         h, w = dx_hw
-        a, b = (h - ph + 1) // 2, (w - pw + 1) // 2
-        if a < 1 or b < 1 or (hi, wi) != ((h - 1) // 2 + 1, (w - 1) // 2 + 1):
+        a, b = (h + 1) // 2, (w + 1) // 2
+        if (hi, wi) != ((h - 1) // 2 + 1, (w - 1) // 2 + 1):
             return None
-        rh, rw = 1 + ph, 1 + pw
         ti, th, tw = choose_tile(n, a, b, 128)
-        hh, hw = th + rh - 1, tw + rw - 1
-        cks = [c_ for c_ in (16, 8) if cin % c_ == 0] if ck is None else [ck]
+        hh, hw = th + 1, tw + 1
+        cks = [c_ for c_ in (16, 8) if cin % c_ == 0]
         forced = getattr(self, 'force_ck', None)
-        if forced and cin % forced == 0 and ck is None:
+        if forced in (8, 16) and cin % forced == 0:
             cks = [forced]
         ck = None
-        for limit in (160 * 1024 // 4, 160 * 1024 // 2, 160 * 1024):       # four, two, one workgroup(s) per CU
+        for limit in (160 * 1024 // 2, 160 * 1024):       # two workgroups per CU (four accumulator sets: ~190 VGPRs), then one
             for c_ in cks:
                 slots = ti * hh * hw * ((c_ + 4) // 4)
-                lds = 2 * ((slots + 3) // 4 * 4 + rh * rw * (c_ // 4) * 32) * 16
+                lds = 2 * ((slots + 3) // 4 * 4 + 9 * (c_ // 4) * 32) * 16
                 if (slots + 255) // 256 <= 8 and lds <= limit:
                     ck = c_
                     break
@@ -469,10 +468,7 @@ class Net:
         p = ConvS1wProb()
         p.x, p.w, p.y = dy_buf.data_ptr(), w_packed.data_ptr(), dx_buf.data_ptr()
         p.N, p.H, p.W, p.Cin, p.Cout, p.Hi, p.Wi = n, h, w, cin, cout, hi, wi
-        p.A, p.B, p.ooh, p.oow, p.RH, p.RW = a, b, ph, pw, rh, rw
-        for u in range(rh):
-            for v in range(rw):
-                p.wt[u * rw + v] = (ph + 1 - 2 * u) * 3 + (pw + 1 - 2 * v)
+        p.A, p.B = a, b
         p.lTI, p.lTH, p.lTW = _log2(ti), _log2(th), _log2(tw)
         p.HH, p.HW, p.CK, p.LD = hh, hw, ck, ck + 4
         p.tiles_a, p.tiles_b = _cdiv(a, th), _cdiv(b, tw)
@@ -483,8 +479,7 @@ class Net:
         p.x_bytes, p.w_bytes, p.y_bytes = dy_buf.numel() * 4, w_packed.numel() * 4, dx_buf.numel() * 4
         p.magic_spp, p.magic_hw, p.magic_hh = magic(p.LD // 4), magic(hw), magic(hh)
         p.magic_nt, p.magic_tb, p.magic_ta = magic(p.n_ntiles), magic(p.tiles_b), magic(p.tiles_a)
-        if not probe:
-            self.debug_convs.append((p, dy_buf, w_packed, dx_buf))
+        self.debug_convs.append((p, dy_buf, w_packed, dx_buf))
         return p
 
     def conv_problem(self, x_buf, x_dims, w_packed, y_buf, y_dims, a, b, out_map, sa, origin, taps, cin, cout,
@@ -1361,18 +1356,11 @@ class Net:
                 return
         st, pad = cv.stride, cv.pad
         if self.use_s1 and self.use_s1w and st == 2 and r == 3 and s == 3 and pad == 1 and cout % 8 == 0 and x.C % 4 == 0:
-            # (one channel chunk for the four classes -- they share a launch: the one the 2x2 window fits with)
-            big = self.s1w_problem(gy, (y.N, y.H, y.W), cv.wd, gx, (x.H, x.W), 1, 1, cout, x.C, acc, probe=True)
-            probs = [self.s1w_problem(gy, (y.N, y.H, y.W), cv.wd, gx, (x.H, x.W), ph, pw, cout, x.C, acc, ck=big.CK)
-                     for ph in (0, 1) for pw in (0, 1)] if big is not None else [None]
-            if all(p_ is not None for p_ in probs):
-                for prob in probs:
-                    npix = prob.N * prob.A * prob.B
-                    rec = Rec(nv.OP_CONV_S1W, 'conv_dgrad bpb_conv_s1w_kernel<%d>' % (prob.CK // 8), 2.0 * npix * prob.RH * prob.RW * prob.Cin * prob.Cout,
-                              4.0 * (npix * prob.Cout + prob.N * prob.Hi * prob.Wi * prob.Cin / 4.0), desc=prob, key=('s1w', prob.CK),
-                              blocks=prob.n_mtiles * prob.n_ntiles, work=prob.RH * prob.RW * prob.Cin)
-                    rec.together = id(cv)          # the parity classes write disjoint pixels of dx: one grouped launch
-                    bwd.add(rec)
+            prob = self.s1w_problem(gy, (y.N, y.H, y.W), cv.wd, gx, (x.H, x.W), cout, x.C, acc)
+            if prob is not None:
+                bwd.add(Rec(nv.OP_CONV_S1W, 'conv_dgrad bpb_conv_s1w_kernel<%d>' % (prob.CK // 8), 2.0 * y.N * y.H * y.W * 9 * cout * x.C,
+                            4.0 * (x.buf.numel() + y.buf.numel()), desc=prob, key=('s1w', prob.CK), blocks=prob.n_mtiles * prob.n_ntiles,
+                            work=9 * prob.Cin))
                 return
         for ph in range(st):
             for pw in range(st):

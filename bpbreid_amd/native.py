@@ -46,9 +46,8 @@ class ConvS1Prob(C.Structure):
 
 class ConvS1wProb(C.Structure):
     _fields_ = [('x', c_fp), ('w', c_fp), ('y', c_fp)] + [
-        (n, C.c_int) for n in ('N', 'H', 'W', 'Cin', 'Cout', 'Hi', 'Wi', 'A', 'B', 'ooh', 'oow', 'RH', 'RW')] + [('wt', C.c_int * 4)] + [
-        (n, C.c_int) for n in ('lTI', 'lTH', 'lTW', 'HH', 'HW', 'CK', 'LD', 'tiles_a', 'tiles_b', 'n_mtiles', 'n_ntiles', 'blk_begin',
-                               'accumulate', 'xr')] + [
+        (n, C.c_int) for n in ('N', 'H', 'W', 'Cin', 'Cout', 'Hi', 'Wi', 'A', 'B', 'lTI', 'lTH', 'lTW', 'HH', 'HW', 'CK', 'LD', 'tiles_a', 'tiles_b',
+                               'n_mtiles', 'n_ntiles', 'blk_begin', 'accumulate', 'xr')] + [
         (n, C.c_uint) for n in ('x_bytes', 'w_bytes', 'y_bytes', 'magic_spp', 'magic_hw', 'magic_hh', 'magic_nt', 'magic_tb', 'magic_ta')]
 
 

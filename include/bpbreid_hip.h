@@ -141,24 +141,22 @@ typedef struct BpbConvS1Prob {
     int tstore;             // 1: epilogue through an LDS transpose, 16-byte stores (plain forward problems of single-tile waves)
 } BpbConvS1Prob;
 
-/* One parity class of the data gradient of a STRIDE-2 3x3 convolution on the lean kernel family (csrc/conv_s1w.hip):
- *   dx[n][2a + ph][2b + pw][:] (+)= sum_{u < RH, v < RW} dy[n][a + u][b + v][:] . W_{wt[u * RW + v]}
- * -- the input pixels of one row / column parity see a 1- or 2-tap window of dy (hrnet.py:240-250, :459-481, the stem :319-323 and
- * resnet.py:31-49 strided 3x3 convolutions, backward).  The four classes of a convolution (windows 1x1, 1x2, 2x1, 2x2) share
- * one grouped launch.  x = dy, Cin = the convolution's output channels, Cout = its input channels. */
+/* Data gradient of a STRIDE-2 3x3 pad-1 convolution on the lean kernel family (csrc/conv_s1w.hip): the four input-pixel parity
+ * classes are dense stride-1 problems on dy with 1x1 / 1x2 / 2x1 / 2x2 windows whose outputs interleave in dx,
+ *   dx[n][2a + ph][2b + pw][:] (+)= sum_{u <= ph, v <= pw} dy[n][a + u][b + v][:] . W[ph + 1 - 2u][pw + 1 - 2v]^T,
+ * and ONE workgroup computes all four for its 128 class pixels (a, b) from one staged tile of dy
+ * (hrnet.py:240-250, :459-481, the stem :319-323 and resnet.py:31-49 strided 3x3 convolutions, backward).
+ * x = dy, Cin = the convolution's output channels, Cout = its input channels. */
 typedef struct BpbConvS1wProb {
     const float* x;         // dy [N][Hi][Wi][Cin]
-    const float* w;         // packed [tap][Cin/4][Cout][4] (the data-gradient packing of bpb_pack_weights)
+    const float* w;         // packed [tap][Cin/4][Cout][4] (the data-gradient packing of bpb_pack_weights), taps in filter order
     float* y;               // dx [N][H][W][Cout]
     int N, H, W, Cin, Cout; // Cin multiple of 8, Cout multiple of 4
-    int Hi, Wi;             // extent of dy
-    int A, B;               // class domain: output pixel (a, b) -> (a * 2 + ooh, b * 2 + oow), a < A, b < B
-    int ooh, oow;
-    int RH, RW;             // window: 1 or 2 rows / columns of dy starting at (a, b); rows / columns beyond dy read zero
-    int wt[4];              // packed-weight tap of window element u * RW + v
+    int Hi, Wi;             // extent of dy = ((H - 1) / 2 + 1, (W - 1) / 2 + 1)
+    int A, B;               // class-pixel domain ((H + 1) / 2, (W + 1) / 2); rows / columns of dy beyond its extent read zero
     int lTI, lTH, lTW;      // M tile = 2^lTI images x 2^lTH x 2^lTW class pixels = 128
-    int HH, HW;             // staged extent of a tile: TH + RH - 1, TW + RW - 1
-    int CK, LD;             // channel chunk (8, 16, 32) and LDS pitch of a staged pixel (CK + 4 floats)
+    int HH, HW;             // staged extent of a tile: TH + 1, TW + 1
+    int CK, LD;             // channel chunk (8, 16) and LDS pitch of a staged pixel (CK + 4 floats)
     int tiles_a, tiles_b, n_mtiles, n_ntiles;
     int blk_begin;
     int accumulate;         // dx += result

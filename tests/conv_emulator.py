@@ -221,24 +221,31 @@ def run_conv_s1(p, x, wpk, y, bias=None, res=None, bn=None):
     return stats
 
 
+S1W_WIN = (0, 0, 0, 0, 1, 1, 2, 2, 3)          # csrc/conv_s1w.hip: window position, filter tap, parity class of the nine products
+S1W_TAP = (4, 5, 7, 8, 3, 6, 1, 2, 0)
+S1W_CLS = (0, 1, 2, 3, 1, 3, 2, 3, 3)
+
+
 def run_conv_s1w(p, x, wpk, y):
-    """Re-executes bpb_conv_s1w_kernel (csrc/conv_s1w.hip: one parity class of a stride-2 3x3 data gradient) at the level of its
-    LDS image: DMA slots of the staged dy tile and of the weight tile from the byte offsets the kernel computes (out of range ->
-    zeros), fragment reads through pixoff / apix / the running B pointer, output pixels at (2a + ooh, 2b + oow).  x = dy
+    """Re-executes bpb_conv_s1w_kernel (csrc/conv_s1w.hip: the data gradient of a stride-2 3x3 pad-1 convolution, four parity
+    classes per workgroup) at the level of its LDS image: DMA slots of the staged dy tile and of the nine-tap weight tile from the
+    byte offsets the kernel computes (out of range -> zeros), fragment reads through pixoff / apix / the immediate B offsets with
+    the kernel's (window, tap, class) table, class (ph, pw) of class pixel (a, b) stored at (2a + ph, 2b + pw).  x = dy
     [N,Hi,Wi,Cin], wpk flat packed weights [tap][Cin/4][Cout][4], y = dx [N,H,W,Cout] (in / out)."""
-    RH, RW = p.RH, p.RW
-    T = RH * RW
+    for it in range(9):      # the table against its definition: r = ph + 1 - 2u, s = pw + 1 - 2v
+        u, v, ph, pw = S1W_WIN[it] >> 1, S1W_WIN[it] & 1, S1W_CLS[it] >> 1, S1W_CLS[it] & 1
+        assert u <= ph and v <= pw and S1W_TAP[it] == (ph + 1 - 2 * u) * 3 + (pw + 1 - 2 * v)
+    assert sorted(S1W_TAP) == list(range(9))
     ti_n, th_n, tw_n = 1 << p.lTI, 1 << p.lTH, 1 << p.lTW
     assert ti_n * th_n * tw_n == 128 and p.n_ntiles == -(-p.Cout // 32)
-    assert p.HH == th_n + RH - 1 and p.HW == tw_n + RW - 1 and p.LD == p.CK + 4
+    assert p.HH == th_n + 1 and p.HW == tw_n + 1 and p.LD == p.CK + 4 and (p.A, p.B) == ((p.H + 1) // 2, (p.W + 1) // 2)
     cin, cout, ld, ck = p.Cin, p.Cout, p.LD, p.CK
     cin4, qn, spp = cin // 4, ck // 4, ld // 4
     npix = ti_n * p.HH * p.HW
     halo_slots = npix * spp
     halo_pad = (halo_slots + 255) // 256 * 256
-    nB = T * qn * 32
-    b_pad = (nB + 255) // 256 * 256
-    assert halo_pad <= 8 * 256 and b_pad <= 4 * 256, 'more DMA pieces per thread than the kernel holds'
+    nB = 9 * qn * 32
+    assert halo_pad <= 8 * 256, 'more DMA pieces per thread than the kernel holds'
     xf, yf = x.reshape(-1), y.reshape(-1)
     KG = ck // 8
     nblk = p.n_mtiles * p.n_ntiles
@@ -257,7 +264,7 @@ def run_conv_s1w(p, x, wpk, y):
         tn = _fdiv(t2, p.tiles_a, p.magic_ta)
         ta = t2 - tn * p.tiles_a
         n0, a0, b0 = tn << p.lTI, ta << p.lTH, tb << p.lTW
-        acc = np.zeros((128, 32))
+        acc = np.zeros((4, 128, 32))
         for cb in range(0, cin, ck):
             halo = np.zeros(halo_pad * 4)
             for idx in range(halo_slots):
@@ -272,38 +279,40 @@ def run_conv_s1w(p, x, wpk, y):
                     off = (((n * p.Hi + ih) * p.Wi + iw) * cin + v * 4) * 4 + cb * 4
                     assert off % 16 == 0 and off + 16 <= p.x_bytes
                     halo[idx * 4:idx * 4 + 4] = xf[off // 4:off // 4 + 4]
-            wts = np.zeros(b_pad * 4)
+            wts = np.zeros(nB * 4)
             for bi in range(nB):
                 n = bi & 31
                 r = bi >> 5
                 q = r & (qn - 1)
                 t = r // qn
-                assert t < T
                 co = min(ntile * 32 + n, cout - 1)
-                off = ((p.wt[t] * cin4 + q) * cout + co) * 16 + (cb // 4) * cout * 16
-                assert off + 16 <= p.w_bytes
+                off = ((t * cin4 + q) * cout + co) * 16 + (cb // 4) * cout * 16
+                assert t < 9 and off + 16 <= p.w_bytes
                 wts[bi * 4:bi * 4 + 4] = wpk[off // 4:off // 4 + 4]
             m = np.arange(128)
             tw, th, ti = m & (tw_n - 1), (m >> p.lTW) & (th_n - 1), m >> (p.lTW + p.lTH)
             pixoff = ((ti * p.HH + th) * p.HW + tw) * ld                  # floats
-            for j in range(T * KG):
-                t, kg = j // KG, j % KG
-                apix = pixoff + ((t // RW) * p.HW + (t % RW)) * ld + kg * 8
+            for s_ in range(9 * KG):
+                kg, it = s_ // 9, s_ % 9
+                w_ = S1W_WIN[it]
+                apix = pixoff + ((w_ >> 1) * p.HW + (w_ & 1)) * ld + kg * 8
                 for half in range(2):
                     a_frag = halo[(apix + half * 4)[:, None] + np.arange(4)[None, :]]                 # [128][4]
-                    bbase = (j * 2 + half) * 32 * 4
+                    bbase = (S1W_TAP[it] * (qn * 512) + kg * 1024 + half * 512) // 4               # floats
                     b_frag = wts[bbase:bbase + 32 * 4].reshape(32, 4)                                  # [n][4]
-                    acc += a_frag @ b_frag.T
-        for mm in range(128):
-            tw, th, ti = mm & (tw_n - 1), (mm >> p.lTW) & (th_n - 1), mm >> (p.lTW + p.lTH)
-            n, a, b = n0 + ti, a0 + th, b0 + tw
-            if n < p.N and a < p.A and b < p.B:
-                base = ((n * p.H + 2 * a + p.ooh) * p.W + 2 * b + p.oow) * cout
-                for nn in range(32):
-                    co = ntile * 32 + nn
-                    if co < cout:
-                        assert (base + co) * 4 + 4 <= p.y_bytes
-                        yf[base + co] = (yf[base + co] if p.accumulate else 0.0) + acc[mm, nn]
+                    acc[S1W_CLS[it]] += a_frag @ b_frag.T
+        for cls in range(4):
+            ph, pw = cls >> 1, cls & 1
+            for mm in range(128):
+                tw, th, ti = mm & (tw_n - 1), (mm >> p.lTW) & (th_n - 1), mm >> (p.lTW + p.lTH)
+                n, i, j = n0 + ti, 2 * (a0 + th) + ph, 2 * (b0 + tw) + pw
+                if n < p.N and i < p.H and j < p.W:
+                    base = ((n * p.H + i) * p.W + j) * cout
+                    for nn in range(32):
+                        co = ntile * 32 + nn
+                        if co < cout:
+                            assert (base + co) * 4 + 4 <= p.y_bytes
+                            yf[base + co] = (yf[base + co] if p.accumulate else 0.0) + acc[cls, mm, nn]
     return None
 
 
