@@ -43,4 +43,6 @@ probe() {
 { echo "== conv_s1 3x3 64x32 32->32 batch 64"; probe s1_b0 "conv_s1" tools/conv_pmc.py 64 32 32 32 3 10
   echo "== the four-branch module step (x4 grouped launch)"; probe s1_x4 "conv_s1" tools/conv_pmc.py x4 10
   echo "== part distance Q=2048 G=20000 P=9 D=512"; probe dist "part_distance_tiled" tools/dist_pmc.py 2048 20000 9 512 2 1; } > $O/pmc_sq.txt 2>&1
+# endurance: 300 steps of the two-stream schedule with the K-split hand-overs (bench.py asserts that none timed out; the loss must stay finite)
+python bench.py --steps 300 --warmup 5 --no-cpu-baseline --no-roofline --no-forward-only --no-eval > $O/bench_300steps.json 2> $O/bench_300steps.err; tail -1 $O/bench_300steps.json | cut -c1-200
 timeout 900 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; tail -2 $O/pytest_gpu.txt
