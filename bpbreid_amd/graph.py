@@ -46,6 +46,10 @@ TUNE = {
     'wgrad1x1_blocks': 512,
     'concat_blocks': 2048,       # head concatenation: 8 workgroups per CU
 }
+for _kv in filter(None, os.environ.get('BPB_TUNE', '').split(',')):      # measurement hook: BPB_TUNE=wgrad16_blocks=384,wgrad16_tpb=8
+    _k, _v = _kv.split('=')
+    assert _k in TUNE, 'BPB_TUNE: unknown constant %r' % _k
+    TUNE[_k] = int(_v)
 
 
 def _pow2ceil(x):
