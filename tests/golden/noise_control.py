@@ -22,6 +22,7 @@ def main(name, threads):
     L.load_reference()
     G.register_hrnet_width('hrnet48', (48, 96, 192, 384))
     G.register_hrnet_width('hrnet_w8', (8, 16, 32, 64))
+    G.register_hrnet_width('hrnet_w16', (16, 32, 64, 128))
     from torchreid import models
     torch.set_num_threads(threads)
     backbone, k, d, n, h, w, ncls, extra = G.MODEL_CASES[name]
