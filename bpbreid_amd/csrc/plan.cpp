@@ -141,6 +141,9 @@ static int run_one(const BpbPlanOp& o, int k, hipStream_t stream)
             case BPB_OP_WGRAD1X1:
                 rc = bpb_conv_wgrad1x1((const BpbWgrad1x1Prob*)o.p[0], (const BpbWgrad1x1Prob*)o.p[1], o.i[0], stream);
                 break;
+            case BPB_OP_WGRAD_C4:
+                rc = bpb_conv_wgrad_c4((const BpbWgradProb*)o.p[0], (const BpbWgradProb*)o.p[1], o.i[0], stream);
+                break;
             case BPB_OP_WGRAD16:
                 rc = bpb_conv_wgrad16((const BpbWgradProb*)o.p[0], (const BpbWgradProb*)o.p[1], o.i[0], stream);
                 break;

@@ -44,6 +44,7 @@ TUNE = {
     'wgrad16_blocks': 256,       # wgrad16: workgroups per problem (64 ... 384 measured: 47.1, 45.3, 42.6, 41.9, 40.2, 42.0 ms per step)
     'wgrad16_tpb': 4,
     'wgrad1x1_blocks': 512,
+    'wgrad_c4_blocks': 512,      # stem weight gradient: workgroups (= split-K slabs of T x 4 x Cout floats)
     'concat_blocks': 2048,       # head concatenation: 8 workgroups per CU
 }
 for _kv in filter(None, os.environ.get('BPB_TUNE', '').split(',')):      # measurement hook: BPB_TUNE=wgrad16_blocks=384,wgrad16_tpb=8
@@ -199,6 +200,7 @@ class Net:
         self.fold_eval_bn = os.environ.get('BPB_FOLD_EVAL_BN', '1') != '0'
         self.dgrad_bn_partials = os.environ.get('BPB_DGRAD_BN', '1') != '0'    # BatchNorm-backward partials from the dgrad epilogue
         self.use_s1w = os.environ.get('BPB_CONV_S1W', '1') != '0'              # 0: strided 3x3 data gradients on the general kernel
+        self.use_wgrad_c4 = os.environ.get('BPB_WGRAD_C4', '1') != '0'         # 0: stem weight gradients on the first-generation kernel
         self.eval_residual_epilogue = os.environ.get('BPB_EVAL_RES', '1') != '0'   # eval plan: residual adds in the conv epilogue
         self.bn_momentum = BN_MOMENTUM     # running-statistics momentum of every BatchNorm of this plan
         # weight-gradient launches (+ their slab reduces) of the backward plan on a second stream (csrc/plan.cpp: bpb_plan_run2)
@@ -1309,8 +1311,25 @@ class Net:
             wp.nsplit = w1.nsplit                              # (the slab reduce record below reads the split count from wp)
             elems = w1.nsplit * x.C * cout
             self.debug_wgrad1x1.append((w1, cv))
+        # the stem (3 input channels = the NHWC4 image): MFMA rows = (tap, channel) pairs, 64-pixel tiles (csrc/wgrad_c4.hip)
+        c4 = self.use_wgrad_c4 and x.C == 4 and 1 < t <= 64 and w1 is None and not use16
+        if c4:
+            ti, th, tw = choose_tile(x.N, y.H, y.W, 64)
+            wp.lTI, wp.lTH, wp.lTW = _log2(ti), _log2(th), _log2(tw)
+            wp.HH, wp.HW, wp.LD = (th - 1) * cv.stride + r, (tw - 1) * cv.stride + s, 4
+            wp.tiles_a, wp.tiles_b = _cdiv(y.H, th), _cdiv(y.W, tw)
+            wp.n_mtiles = _cdiv(x.N, ti) * wp.tiles_a * wp.tiles_b
+            wp.n_citiles, wp.n_cotiles, wp.n_tapgroups, wp.ntw = 1, _cdiv(cout, 64), 1, 2
+            wp.nsplit = max(1, min(wp.n_mtiles, TUNE['wgrad_c4_blocks'] // wp.n_cotiles))
+            wp.magic_hw, wp.magic_hh, wp.magic_spp = magic(wp.HW), magic(wp.HH), magic(1)
+            elems = wp.nsplit * t * x.C * cout
+            c4 = 2 * ((ti * wp.HH * wp.HW + 3) // 4 * 4 + 64 * 16) * 16 <= 160 * 1024
         n_before = len(bwd)
-        if w1 is not None:
+        if c4:
+            bwd.add(Rec(nv.OP_WGRAD_C4, 'conv_wgrad bpb_wgrad_c4_kernel<%d>' % (1 if t <= 32 else 2), 2.0 * y.N * y.H * y.W * t * cin_real * cout,
+                        4.0 * (x.buf.numel() + y.buf.numel()), desc=wp, key=('wgc4', t <= 32), blocks=wp.nsplit * wp.n_cotiles,
+                        work=float(_cdiv(wp.n_mtiles, wp.nsplit))))
+        elif w1 is not None:
             bwd.add(Rec(nv.OP_WGRAD1X1, 'conv_wgrad bpb_wgrad1x1_kernel<%d>' % w1.lwm, 2.0 * y.N * y.H * y.W * x.C * cout,
                         4.0 * (x.buf.numel() + y.buf.numel()), desc=w1, key=('wg1',), blocks=w1.nsplit * w1.n_citiles * w1.n_cotiles,
                         work=float(_cdiv(w1.n_ptiles, w1.nsplit))))

@@ -359,6 +359,7 @@ typedef enum BpbOpKind {
     BPB_OP_BILINEAR_MULTI_BWD = 29, /* p0 device BpbBilinearBwdDesc[], p1 host copy, i0 n */
     BPB_OP_WGRAD1X1 = 30,          /* p0 device BpbWgrad1x1Prob[], p1 host copy, i0 nprobs */
     BPB_OP_CONV_S1W = 31,          /* p0 device BpbConvS1wProb[], p1 host copy, i0 nprobs */
+    BPB_OP_WGRAD_C4 = 32,          /* p0 device BpbWgradProb[], p1 host copy, i0 nprobs */
 } BpbOpKind;
 
 // generic op record; slot meaning per kind is documented next to each case; i[10] = stream slot (0 = the caller's stream, 1..3 = branch streams,
@@ -387,6 +388,10 @@ int bpb_conv_igemm(const BpbConvProb* d_probs, const BpbConvProb* h_probs, int n
 int bpb_wgrad16_init(void);
 int bpb_conv_wgrad16(const BpbWgradProb* d_probs, const BpbWgradProb* h_probs, int nprobs, hipStream_t stream);
 /* 1x1 stride-1 filters with Cin, Cout >= 64: x and dy streamed once (resnet.py:119-127, hrnet.py:104-110,319-350) */
+/* stem filters (3 input channels = the NHWC4 image, 3x3 or 7x7, hrnet.py:319-320 / resnet.py:211-213): MFMA rows = (tap, channel)
+ * pairs, x and dy staged once per 64-pixel tile (csrc/wgrad_c4.hip); same descriptor and slab layout as bpb_conv_wgrad */
+int bpb_wgrad_c4_init(void);
+int bpb_conv_wgrad_c4(const BpbWgradProb* d_probs, const BpbWgradProb* h_probs, int nprobs, hipStream_t stream);
 int bpb_wgrad1x1_init(void);
 int bpb_conv_wgrad1x1(const BpbWgrad1x1Prob* d_probs, const BpbWgrad1x1Prob* h_probs, int nprobs, hipStream_t stream);
 int bpb_wgrad_reduce_multi(const BpbWgradReduceDesc* d_descs, const BpbWgradReduceDesc* h_descs, int n, int total_blocks,

@@ -355,6 +355,80 @@ def run_wgrad(p, x, dy):
     return out
 
 
+def run_wgrad_c4(p, x, dy):
+    """Re-executes bpb_wgrad_c4_kernel (csrc/wgrad_c4.hip: the stem weight gradient, MFMA rows = (tap, channel) pairs) at the level
+    of its LDS image: per 64-pixel tile the staged image of x (one 16-byte slot per pixel, out of range -> zeros) and the dy tile
+    from the byte offsets the kernel computes, the A operand as the gather pixel offset + per-lane tap offset, slab rows written by
+    (wave, M tile, MFMA row) exactly as the epilogue does.  x [N,Hi,Wi,4], dy [N,A,B,Cout] -> dW [T][4][Cout] (slabs summed)."""
+    assert p.Cin == 4 and p.lTI + p.lTH + p.lTW == 6 and 1 <= p.T <= 64
+    ti_n, th_n, tw_n = 1 << p.lTI, 1 << p.lTH, 1 << p.lTW
+    R = p.T // p.S
+    assert p.HH == (th_n - 1) * p.sa + R and p.HW == (tw_n - 1) * p.sa + p.S
+    mtw = 1 if p.T <= 32 else 2
+    xf, dyf = x.reshape(-1), dy.reshape(-1)
+    cout = p.Cout
+    halo_slots = ti_n * p.HH * p.HW
+    ws = np.zeros((p.nsplit, p.T, 4, cout))
+    written = np.zeros((p.nsplit, p.T, 4, cout), dtype=bool)
+    per = -(-p.n_mtiles // p.nsplit)
+    for cot in range(p.n_cotiles):
+        co0 = cot * 64
+        for split in range(p.nsplit):
+            acc = np.zeros((4, mtw, 32, 64))          # [wave][M tile of the wave][row][co]
+            for mtile in range(split * per, min(p.n_mtiles, split * per + per)):
+                tb, t2 = mtile % p.tiles_b, mtile // p.tiles_b
+                ta, tn = t2 % p.tiles_a, t2 // p.tiles_a
+                n0, a0, b0 = tn << p.lTI, ta << p.lTH, tb << p.lTW
+                halo = np.zeros((halo_slots, 4))
+                for idx in range(halo_slots):
+                    t = _fdiv(idx, p.HW, p.magic_hw)
+                    hc = idx - t * p.HW
+                    ti = _fdiv(t, p.HH, p.magic_hh)
+                    hr = t - ti * p.HH
+                    n, ih, iw = n0 + ti, a0 * p.sa + hr + p.ih0, b0 * p.sa + hc + p.iw0
+                    if n < p.N and 0 <= ih < p.Hi and 0 <= iw < p.Wi:
+                        off = ((n * p.Hi + ih) * p.Wi + iw) * 16
+                        assert off + 16 <= p.x_bytes
+                        halo[idx] = xf[off // 4:off // 4 + 4]
+                dyt = np.zeros((64, 64))
+                for idx in range(64 * 16):
+                    v, m = idx & 15, idx >> 4
+                    tw, th, ti = m & (tw_n - 1), (m >> p.lTW) & (th_n - 1), m >> (p.lTW + p.lTH)
+                    n, a, b = n0 + ti, a0 + th, b0 + tw
+                    co = co0 + v * 4
+                    if n < p.N and a < p.A and b < p.B and co < cout:
+                        off = (((n * p.A + a) * p.B + b) * cout + co) * 4
+                        assert off + 16 <= p.dy_bytes
+                        dyt[m, v * 4:v * 4 + 4] = dyf[off // 4:off // 4 + 4]
+                hflat = halo.reshape(-1)
+                for wave in range(4):
+                    if wave * 8 >= p.T:
+                        continue
+                    for j in range(mtw):
+                        if j == 1 and (wave + 4) * 8 >= p.T:
+                            continue
+                        for row in range(32):
+                            tap = min((wave + 4 * j) * 8 + (row >> 2), p.T - 1)
+                            r_, s_ = tap // p.S, tap % p.S
+                            tapoff = (r_ * p.HW + s_) * 4 + (row & 3)                # floats
+                            for m in range(64):
+                                tw, th, ti = m & (tw_n - 1), (m >> p.lTW) & (th_n - 1), m >> (p.lTW + p.lTH)
+                                xo = ((ti * p.HH + th * p.sa) * p.HW + tw * p.sa) * 4
+                                acc[wave, j, row] += hflat[xo + tapoff] * dyt[m]
+            for wave in range(4):
+                for j in range(mtw):
+                    for row in range(32):
+                        tap, ci = (wave + 4 * j) * 8 + (row >> 2), row & 3
+                        if tap < p.T:
+                            for col in range(64):
+                                if co0 + col < cout:
+                                    assert not written[split, tap, ci, co0 + col]
+                                    written[split, tap, ci, co0 + col] = True
+                                    ws[split, tap, ci, co0 + col] = acc[wave, j, row, col]
+    assert written.all(), 'slab elements that no wave writes'
+    return ws.sum(0)
+
+
 def run_wgrad16(p, x, dy):
     """Re-executes bpb_wgrad16_kernel (csrc/wgrad16.hip) at the level of its planar LDS image: DMA slot -> global offset for
     the x halo and the dy tile, the per-lane k-step offsets xo / bo / tapoff, the quadrant a wave owns and the slab element

@@ -203,7 +203,12 @@ def test_conv_descriptors_forward_dgrad_wgrad(case):
         assert np.allclose(gx, xr.grad.permute(0, 2, 3, 1).numpy(), atol=1e-9), 'dgrad geometry'
     # ---- weight gradient
     wp = net.debug_wgrads[0][0]
-    dw = emu.run_wgrad(wp, x_nhwc, gy.numpy())                           # [T][Cin_pad][Cout]
+    used_c4 = any(r.kind == nv.OP_WGRAD_C4 for r in net.bwd)
+    assert used_c4 == (cin == 3 and 1 < k * k <= 64), 'the stem weight-gradient kernel takes the 3-channel spatial filters'
+    if used_c4:              # csrc/wgrad_c4.hip: MFMA rows = (tap, channel) pairs, 64-pixel tiles
+        dw = emu.run_wgrad_c4(wp, x_nhwc, gy.numpy())                    # [T][4][Cout]
+    else:
+        dw = emu.run_wgrad(wp, x_nhwc, gy.numpy())                       # [T][Cin_pad][Cout]
     used16 = any(r.kind == nv.OP_WGRAD16 for r in net.bwd)
     if k == 3 and pad == 1 and cpad >= 16 and (stride == 1 or case[:2] in ((2, 16), (3, 12))):
         assert used16, 'second-generation weight-gradient kernel not selected'
