@@ -3,7 +3,7 @@ measurement build of csrc/conv_s1.hip (-DBPB_S1_TRACE: every wave stamps s_memti
 landed / MFMA loop done / exit and records the SIMD it ran on).  Answers: where does a wave's lifetime go, how many waves of
 a SIMD are in their MFMA loop at the same time, how long is the launch's tail.
 
-    python tools/s1_trace.py [x4|x3|x2|b0|b1|b2|b3] [tile mt,lwn,nt] [ck]
+    python tools/s1_trace.py [x4|x3|x2|b0|b1|b2|b3 | l1a|l1b|l1c|l2a|l2b|l3a|l3b|l4a|l4b (1x1 shapes)] [tile mt,lwn,nt] [ck]
 """
 import os, sys, subprocess, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -39,7 +39,11 @@ nv.init_device()
 N = 64
 BR = [(64, 32, 32, 32, 3), (32, 16, 64, 64, 3), (16, 8, 128, 128, 3), (8, 4, 256, 256, 3)]
 what = sys.argv[1] if len(sys.argv) > 1 else 'x4'
-shapes = {'x4': BR, 'x3': BR[:3], 'x2': BR[:2], 'b0': BR[:1], 'b1': BR[1:2], 'b2': BR[2:3], 'b3': BR[3:4]}[what]
+ONE = {'l1a': (64, 32, 256, 64, 1), 'l1b': (64, 32, 64, 256, 1), 'l1c': (64, 32, 64, 64, 1),          # layer 1 (HRNet and ResNet-50)
+       'l2a': (32, 16, 128, 512, 1), 'l2b': (32, 16, 512, 128, 1), 'l3a': (16, 8, 256, 1024, 1), 'l3b': (16, 8, 1024, 256, 1),
+       'l4a': (16, 8, 512, 2048, 1), 'l4b': (16, 8, 2048, 512, 1)}                                      # ResNet-50 layers 2-4
+shapes = {'x4': BR, 'x3': BR[:3], 'x2': BR[:2], 'b0': BR[:1], 'b1': BR[1:2], 'b2': BR[2:3], 'b3': BR[3:4],
+          **{k_: [v_] for k_, v_ in ONE.items()}}[what]
 net = Net(dev)
 if len(sys.argv) > 2 and sys.argv[2] != '-':
     net.force_tile = tuple(int(v) for v in sys.argv[2].split(','))
