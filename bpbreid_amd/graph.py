@@ -200,6 +200,7 @@ class Net:
         self.fold_eval_bn = os.environ.get('BPB_FOLD_EVAL_BN', '1') != '0'
         self.dgrad_bn_partials = os.environ.get('BPB_DGRAD_BN', '1') != '0'    # BatchNorm-backward partials from the dgrad epilogue
         self.use_s1w = os.environ.get('BPB_CONV_S1W', '1') != '0'              # 0: strided 3x3 data gradients on the general kernel
+        self.tune_1x1 = os.environ.get('BPB_S1_1X1_TILES', '1') != '0'         # 0: round-3 tile rule for stand-alone 1x1 convolutions
         self.use_wgrad_c4 = os.environ.get('BPB_WGRAD_C4', '1') != '0'         # 0: stem weight gradients on the first-generation kernel
         self.eval_residual_epilogue = os.environ.get('BPB_EVAL_RES', '1') != '0'   # eval plan: residual adds in the conv epilogue
         self.bn_momentum = BN_MOMENTUM     # running-statistics momentum of every BatchNorm of this plan
@@ -342,6 +343,7 @@ class Net:
         # (~600 instructions), few enough that the deep low-resolution branches still split into many workgroups
         cands = [(1, 1), (2, 1), (1, 2), (2, 2)]
         cands = [c_ for c_ in cands if c_[1] * 32 <= max(32, _pow2ceil(cout))]
+        want_ck32 = False
         forced = getattr(self, 'force_tile', None)         # tests pin (mt, lwn, nt) to cover every kernel variant
         if forced is not None:
             mt_r, lwn, nt = forced
@@ -378,6 +380,17 @@ class Net:
                 lwn = 1 if cout >= 128 else 0
                 if k2 >= 256 and cout >= 1024 and wgs(2, nt, lwn) >= 512:
                     mt_r = 2
+                # 1x1 launches that stand alone (ResNet-50 layers 2-4, both directions; tools/s1_sweep.py 1x1 ->
+                # profiles/r04_s1_sweep_1x1.txt): with 64-pixel tiles the launch is 1.33 / 2.67 generations of workgroups (a third
+                # of the chip idles through the last one: tools/s1_trace.py l3a) and a workgroup's prologue + epilogue are a
+                # quarter of its life.  128-pixel tiles with 32-channel chunks: x 64 channels where the convolution narrows
+                # (K >= 256: 1024->256 59 -> 53 us, 2048->512 169 -> 155), x 128 where it widens (256->1024 56 -> 44, 512->2048
+                # 165 -> 153 us) -- as long as every CU still gets a workgroup.
+                if self.tune_1x1 and not in_region and stride == 1:
+                    if cin >= 256 and 128 <= cout <= cin and wgs(2, 1, 1) >= 256:
+                        mt_r, nt, lwn, want_ck32 = 2, 1, 1, True
+                    elif cin >= 128 and cout >= 4 * cin and wgs(2, 2, 1) >= 512:
+                        mt_r, nt, lwn, want_ck32 = 2, 2, 1, True
         pad256 = lambda v_: (v_ + 255) // 256 * 256
         cks = [c_ for c_ in (32, 16, 8) if cin % c_ == 0]
         assert cks, 'conv_s1: Cin must be a multiple of 8'
@@ -395,7 +408,9 @@ class Net:
                 halo, wts = pad256(halo_slots), pad256(w_slots)          # DMA pieces of 256 x 16 B
                 return halo, wts, max(8192, 2 * ((halo_slots + 3) // 4 * 4 + w_slots) * 16)     # LDS: regions packed, two buffers
             ok = [c_ for c_ in cks if sizes(c_)[0] <= 12 * 256 and sizes(c_)[1] <= 12 * 256]   # <= 12 DMA pieces per thread
-            for limit_kb in (TUNE['s1_lds_kb'], 53, 79, 160):    # >= 3, 3, 2, 1 workgroups per CU
+            # (the 128-pixel 1x1 tiles above: 32-channel chunks at two workgroups per CU beat 16-channel chunks at three)
+            limits = (79, 160) if (want_ck32 and forced is None and (mt_r, r) == (2, 1)) else (TUNE['s1_lds_kb'], 53, 79, 160)
+            for limit_kb in limits:    # >= 3, 3, 2, 1 workgroups per CU
                 fit = [c_ for c_ in ok if sizes(c_)[2] <= limit_kb * 1024]
                 if fit:
                     ck = fit[0]

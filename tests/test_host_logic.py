@@ -152,6 +152,45 @@ def test_grouped_conv_policies_k_split_unpadded_halo_transposed_epilogue(monkeyp
     assert any(p.split for p in fwd) and any(p.split for p in dgrad)
 
 
+def test_standalone_1x1_convolutions_take_128_pixel_tiles_where_every_cu_still_gets_a_workgroup(monkeypatch):
+    """Plan-time tile rule of 1x1 launches that stand alone (ResNet-50 layers 2-4, profiles/r04_s1_sweep_1x1.txt): 128 pixels x 64
+    channels with 32-channel chunks where the convolution narrows (K >= 256), 128 x 128 where it widens by 4; the round-3 tile at
+    small batches (too few workgroups), inside fork regions (one kernel variant per grouped launch) and with the switch off."""
+    def tile(n, h, w, cin, cout, region=False):
+        net = Net(torch.device('cpu'))
+        if region:
+            net.fork(2)
+            net.set_slot(0)
+        x = Act(net, n, h, w, cin)
+        wt = torch.zeros(cout, cin, 1, 1)
+        wt.grad = torch.zeros_like(wt)
+        net.conv(x, wt, 1, 0)
+        if region:
+            net.set_slot(1)
+            x2 = Act(net, n, h, w, cin)
+            wt2 = torch.zeros(cout, cin, 1, 1)
+            wt2.grad = torch.zeros_like(wt2)
+            net.conv(x2, wt2, 1, 0)
+            net.set_slot(0)
+            net.join(2)
+        net.finalize(train_backward=False)
+        p = net.debug_convs[0][0]
+        return p.mt_r, p.lwn, p.nt, p.CK
+
+    assert tile(64, 16, 8, 1024, 256) == (2, 1, 1, 32)        # narrowing, 256 workgroups
+    assert tile(64, 16, 8, 2048, 512) == (2, 1, 1, 32)
+    assert tile(64, 32, 16, 512, 128) == (2, 1, 1, 32)
+    assert tile(64, 16, 8, 256, 1024) == (2, 1, 2, 32)        # widening: 128 x 128 tiles, two workgroups per CU
+    assert tile(64, 16, 8, 512, 2048) == (2, 1, 2, 32)
+    assert tile(64, 64, 32, 64, 256) == (1, 1, 2, 32)         # layer 1: K = 64, the round-3 tile
+    assert tile(64, 64, 32, 256, 64) == (1, 0, 2, 32)
+    assert tile(8, 16, 8, 1024, 256) == (1, 1, 2, 32)         # batch 8: 32 workgroups of the large tile -> not used
+    assert tile(64, 16, 8, 1024, 256, region=True) == (1, 1, 2, 32)
+    monkeypatch.setenv('BPB_S1_1X1_TILES', '0')
+    assert tile(64, 16, 8, 1024, 256) == (1, 1, 2, 32)
+    assert tile(64, 16, 8, 512, 2048) == (2, 1, 2, 16)
+
+
 @pytest.mark.parametrize('case', CONV_CASES)
 def test_conv_descriptors_forward_dgrad_wgrad(case):
     n, h, w, cin, cout, k, stride, pad = case

@@ -12,6 +12,9 @@ nv.init_device()
 N = 64
 SHAPES = [(64, 32, 32, 32, 3), (32, 16, 64, 64, 3), (16, 8, 128, 128, 3), (8, 4, 256, 256, 3), (64, 32, 64, 64, 3),
           (64, 32, 64, 256, 1), (64, 32, 256, 64, 1), (16, 8, 512, 2048, 1), (16, 8, 2048, 512, 1), (16, 8, 512, 512, 3)]
+if len(sys.argv) > 1 and sys.argv[1] == '1x1':      # the 1x1 shapes of layer 1 (HRNet, ResNet-50) and of ResNet-50's layers 2-4, forward orientation
+    SHAPES = [(64, 32, 64, 64, 1), (64, 32, 64, 256, 1), (64, 32, 256, 64, 1), (32, 16, 256, 128, 1), (32, 16, 128, 512, 1), (32, 16, 512, 128, 1),
+              (16, 8, 512, 256, 1), (16, 8, 256, 1024, 1), (16, 8, 1024, 256, 1), (16, 8, 1024, 512, 1), (16, 8, 512, 2048, 1), (16, 8, 2048, 512, 1)]
 TILES = [(1, 0, 1), (2, 0, 1), (1, 1, 1), (2, 1, 1), (1, 0, 2), (2, 0, 2), (1, 1, 2), (2, 1, 2)]
 CKS = [32, 16, 8]
 
@@ -73,8 +76,10 @@ for sh in SHAPES:
     best = min(res.items(), key=lambda kv: kv[1])
     print('%3dx%-3d %4d->%-4d k%d  default %s %6.1f us (%5.1f TF) | best %s %6.1f us (%5.1f TF) | %s' % (
         h, w, cin, cout, k, dcfg, dus, flops / dus * 1e-6, best[0], best[1], flops / best[1] * 1e-6,
-        ' '.join('%s:%.0f' % (''.join(map(str, c_)), u) for c_, u in sorted(res.items(), key=lambda kv: kv[1])[:8])), flush=True)
+        ' '.join('%s:%.0f' % (''.join(map(str, c_)), u) for c_, u in sorted(res.items(), key=lambda kv: kv[1])[:(24 if len(sys.argv) > 1 else 8)])), flush=True)
 
+if len(sys.argv) > 1:
+    sys.exit(0)
 # the four-branch module step as one grouped launch, uniform wave tile
 MODULE = SHAPES[:4]
 flops = sum(2.0 * N * h * w * k * k * cin * cout for (h, w, cin, cout, k) in MODULE)
