@@ -89,6 +89,14 @@ def choose_tile(n, a, b, pixels):
     return best[1], best[2], best[3]
 
 
+def pack_ib(t, cin_pad):
+    """Input channels per workgroup tile of bpb_pack_weights (csrc/conv_igemm.hip): a multiple of 4 with IB * T <= 196 (the LDS
+    row of one output channel), at most 64."""
+    ib = 64 if t == 1 else 16 if t <= 12 else max(4, min(64, (196 // t) // 4 * 4))   # (16 divides every HRNet / ResNet width)
+    assert ib * t <= 196, 'bpb_pack_weights: a %d-tap filter does not fit the packing tile' % t
+    return min(ib, (cin_pad + 3) // 4 * 4)
+
+
 class Rec:
     """One record of a plan before freezing: either a ready PlanOp (`op`) or a mergeable descriptor (`desc` + `key`)."""
 
@@ -638,14 +646,16 @@ class Net:
             pk.wd = cv.wd.data_ptr() if cv.wd is not None else None
             pk.Cout, pk.Cin, pk.Cin_pad, pk.T = cout, cin_real, cin_pad, t
             pk.blk_begin = blk
+            pk.IB = pack_ib(t, cin_pad)
             pk.scale = None
             cv.folded = cv.bn is not None and cv.bias is None and self.fold_eval_bn
             cv.wf_eval = torch.empty_like(cv.wf) if cv.folded else cv.wf
             pe = packs_eval[k]
             pe.w, pe.wf, pe.wd = cv.weight.data_ptr(), cv.wf_eval.data_ptr(), None
-            pe.Cout, pe.Cin, pe.Cin_pad, pe.T, pe.blk_begin = cout, cin_real, cin_pad, t, blk
+            pe.Cout, pe.Cin, pe.Cin_pad, pe.T, pe.blk_begin, pe.IB = cout, cin_real, cin_pad, t, blk, pk.IB
             pe.scale = cv.bn.scale.data_ptr() if cv.folded else None
-            blk += -(-(t * cin_pad * cout) // 256)
+            assert cout % 4 == 0 or cv.wd is None, 'bpb_pack_weights: the data-gradient packing needs Cout % 4 == 0'
+            blk += _cdiv(cout, 16) * _cdiv(cin_pad, pk.IB)
         pack_eval_rec = None
         if self.convs:
             dpacks = self._dev_struct(packs)

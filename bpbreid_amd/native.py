@@ -94,7 +94,7 @@ GEMM_MAX = 24
 
 class PackProb(C.Structure):
     _fields_ = [('w', c_fp), ('wf', c_fp), ('wd', c_fp), ('Cout', C.c_int), ('Cin', C.c_int), ('Cin_pad', C.c_int),
-                ('T', C.c_int), ('blk_begin', C.c_int), ('scale', c_fp)]
+                ('T', C.c_int), ('blk_begin', C.c_int), ('IB', C.c_int), ('scale', c_fp)]
 
 
 class FuseArgs(C.Structure):

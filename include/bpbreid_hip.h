@@ -208,6 +208,7 @@ typedef struct BpbPackProb {
     float* wd;
     int Cout, Cin, Cin_pad, T;
     int blk_begin;
+    int IB;               // input channels per workgroup tile (multiple of 4, IB * T <= 196): blocks = ceil(Cout / 16) * ceil(Cin_pad / IB)
     const float* scale;   // optional [Cout]: wf is multiplied by scale[co] (eval mode: BatchNorm folded into the weights)
 } BpbPackProb;
 

@@ -31,6 +31,51 @@ def pack_dgrad(w, cin_pad):
     return out.reshape(-1)
 
 
+def run_pack(w, cin_pad, ib, scale=None, dgrad=True):
+    """bpb_pack_weights_kernel's workgroup loop (16 output channels x `ib` input channels x all taps per tile, csrc/conv_igemm.hip):
+    returns (wf, wd, number of workgroups); every packed element must be written exactly once."""
+    cout, cin, r, s = w.shape
+    t = r * s
+    wflat = w.reshape(-1)
+    wf = np.full(t * cin_pad * cout, np.nan, dtype=w.dtype)
+    wd = np.full(t * cout * cin_pad, np.nan, dtype=w.dtype) if dgrad else None
+    tiles_ci = -(-cin_pad // ib)
+    nblk = -(-cout // 16) * tiles_ci
+    for bid in range(nblk):
+        c0, i0 = (bid // tiles_ci) * 16, (bid % tiles_ci) * ib
+        nci, ncp = min(ib, cin - i0), min(ib, cin_pad - i0)
+        tile = np.zeros((16, 197), dtype=w.dtype)
+        rl = max(nci, 0) * t
+        assert rl <= 197
+        for rr in range(16):
+            if c0 + rr < cout:
+                base = ((c0 + rr) * cin + i0) * t
+                tile[rr, :rl] = wflat[base:base + rl]
+        nq = ncp >> 2
+        for pr in range(t * nq):
+            tt, ql = pr // nq, pr % nq
+            for lane in range(64):
+                co_l, e = lane >> 2, lane & 3
+                co, cil = c0 + co_l, ql * 4 + e
+                if co < cout:
+                    v = tile[co_l, cil * t + tt] * (scale[co] if scale is not None else 1.0) if cil < nci else 0.0
+                    idx = ((tt * (cin_pad >> 2) + (i0 >> 2) + ql) * cout + co) * 4 + e
+                    assert np.isnan(wf[idx])
+                    wf[idx] = v
+        if dgrad:
+            for pr in range(t * 4):
+                tt, cq = pr >> 2, pr & 3
+                for c in range(ncp * 4):
+                    cil, e = c >> 2, c & 3
+                    co_l = cq * 4 + e
+                    co = c0 + co_l
+                    if co < cout:
+                        idx = ((tt * (cout >> 2) + (c0 >> 2) + cq) * cin_pad + i0 + cil) * 4 + e
+                        assert np.isnan(wd[idx])
+                        wd[idx] = tile[co_l, cil * t + tt] if cil < nci else 0.0
+    return wf, wd, nblk
+
+
 def run_conv(p, x, wpk, y, bias=None):
     """p: object with the ConvProb fields; x [N,Hi,Wi,Cin], wpk flat packed weights, y [N,Ho,Wo,Cout] (in/out)."""
     ti_n, th_n, tw_n = 1 << p.lTI, 1 << p.lTH, 1 << p.lTW

@@ -46,6 +46,40 @@ def nchw(t):
     return t.permute(0, 3, 1, 2).contiguous()
 
 
+@pytest.mark.parametrize('shape', [(64, 3, 7), (64, 3, 3), (32, 32, 3), (48, 24, 3), (256, 64, 1), (64, 256, 1), (36, 96, 1), (20, 8, 5)])
+def test_weight_packing_equals_the_index_definition(shape):
+    """bpb_pack_weights (tiles of 16 output channels x IB input channels through LDS) against the two layouts' definitions
+    (tests/conv_emulator.py pack_fwd / pack_dgrad), with and without the eval plan's BatchNorm scale; several problems per launch."""
+    import conv_emulator as emu
+    from bpbreid_amd.graph import pack_ib
+    cout, cin, k = shape
+    t = k * k
+    cin_pad = 4 if cin == 3 else cin
+    g = torch.Generator().manual_seed(cout * 131 + cin)
+    w = torch.randn(cout, cin, k, k, generator=g)
+    scale = torch.randn(cout, generator=g)
+    wd_, sd_ = w.to(DEV), scale.to(DEV)
+    packs = (nv.PackProb * 2)()
+    outs = []
+    blk = 0
+    for i, sc in enumerate((None, sd_)):
+        wf = torch.full((t * cin_pad * cout,), float('nan'), device=DEV)
+        wd = torch.full((t * cin_pad * cout,), float('nan'), device=DEV) if sc is None else None
+        pk = packs[i]
+        pk.w, pk.wf, pk.wd = wd_.data_ptr(), wf.data_ptr(), (wd.data_ptr() if wd is not None else None)
+        pk.Cout, pk.Cin, pk.Cin_pad, pk.T, pk.blk_begin, pk.IB = cout, cin, cin_pad, t, blk, pack_ib(t, cin_pad)
+        pk.scale = sc.data_ptr() if sc is not None else None
+        blk += -(-cout // 16) * -(-cin_pad // pk.IB)
+        outs.append((wf, wd))
+    dev = torch.frombuffer(bytearray(C.string_at(C.addressof(packs), C.sizeof(packs))), dtype=torch.uint8).to(DEV)
+    nv.call('bpb_pack_weights', dev.data_ptr(), 2, blk, nv.stream())
+    torch.cuda.synchronize()
+    wn = w.numpy()
+    assert np.array_equal(outs[0][0].cpu().numpy(), emu.pack_fwd(wn, cin_pad))
+    assert np.array_equal(outs[0][1].cpu().numpy(), emu.pack_dgrad(wn, cin_pad))
+    assert np.array_equal(outs[1][0].cpu().numpy(), emu.pack_fwd(wn * scale.numpy()[:, None, None, None], cin_pad))
+
+
 def test_mfma_f32_layout_via_identity_conv():
     """A = I check with an asymmetric B (guide rule 16): 1x1 conv with identity weights must copy, with a
     permutation matrix must permute channels, nothing transposed."""

@@ -152,6 +152,26 @@ def test_grouped_conv_policies_k_split_unpadded_halo_transposed_epilogue(monkeyp
     assert any(p.split for p in fwd) and any(p.split for p in dgrad)
 
 
+@pytest.mark.parametrize('shape', [(64, 3, 7), (64, 3, 3), (32, 32, 3), (48, 24, 3), (256, 64, 1), (64, 256, 1), (36, 96, 1), (20, 8, 5)])
+def test_weight_packing_tiles_write_every_packed_element_once(shape):
+    """bpb_pack_weights as tiles of 16 output channels x IB input channels through LDS: the emulated workgroup loop reproduces the
+    forward and data-gradient layouts (incl. the BatchNorm scale of the eval plan, zero padding of the 3-channel stem, ragged
+    channel tiles) and graph.pack_ib keeps a tile row inside the kernel's LDS row."""
+    from bpbreid_amd.graph import pack_ib
+    cout, cin, k = shape
+    rng = np.random.default_rng(cout * 131 + cin)
+    w = rng.standard_normal((cout, cin, k, k)).astype(np.float32)
+    cin_pad = 4 if cin == 3 else cin
+    ib = pack_ib(k * k, cin_pad)
+    assert ib % 4 == 0 and ib * k * k <= 196
+    scale = rng.standard_normal(cout).astype(np.float32)
+    wf, wd, nblk = emu.run_pack(w, cin_pad, ib, scale=None)
+    assert nblk == -(-cout // 16) * -(-cin_pad // ib)
+    assert np.array_equal(wf, emu.pack_fwd(w, cin_pad)) and np.array_equal(wd, emu.pack_dgrad(w, cin_pad))
+    wfs, _, _ = emu.run_pack(w, cin_pad, ib, scale=scale, dgrad=False)
+    assert np.array_equal(wfs, emu.pack_fwd(w * scale[:, None, None, None], cin_pad))
+
+
 def test_standalone_1x1_convolutions_take_128_pixel_tiles_where_every_cu_still_gets_a_workgroup(monkeypatch):
     """Plan-time tile rule of 1x1 launches that stand alone (ResNet-50 layers 2-4, profiles/r04_s1_sweep_1x1.txt): 128 pixels x 64
     channels with 32-channel chunks where the convolution narrows (K >= 256), 128 x 128 where it widens by 4; the round-3 tile at
