@@ -141,6 +141,10 @@ static int run_one(const BpbPlanOp& o, int k, hipStream_t stream)
             case BPB_OP_WGRAD1X1:
                 rc = bpb_conv_wgrad1x1((const BpbWgrad1x1Prob*)o.p[0], (const BpbWgrad1x1Prob*)o.p[1], o.i[0], stream);
                 break;
+            case BPB_OP_CONV_C4:   // p0 x, p1 w, p2 y, p3 bias, p4 stats, i0 N, i1 Hi, i2 Wi, i3 R, i4 Cout, i5 relu, i6 nblk
+                rc = bpb_conv_c4((const float*)o.p[0], (const float*)o.p[1], (float*)o.p[2], (const float*)o.p[3], (double*)o.p[4], o.i[0], o.i[1],
+                                 o.i[2], o.i[3], o.i[4], o.i[5], o.i[6], stream);
+                break;
             case BPB_OP_WGRAD_C4:
                 rc = bpb_conv_wgrad_c4((const BpbWgradProb*)o.p[0], (const BpbWgradProb*)o.p[1], o.i[0], stream);
                 break;

@@ -44,6 +44,7 @@ TUNE = {
     'wgrad16_blocks': 256,       # wgrad16: workgroups per problem (64 ... 384 measured: 47.1, 45.3, 42.6, 41.9, 40.2, 42.0 ms per step)
     'wgrad16_tpb': 4,
     'wgrad1x1_blocks': 512,
+    'conv_c4_blocks': 512,       # stem forward: workgroups (each walks a contiguous range of 8 x 16-pixel tiles; two per CU)
     'wgrad_c4_blocks': 512,      # stem weight gradient: workgroups (= split-K slabs of T x 4 x Cout floats)
     'concat_blocks': 2048,       # head concatenation: 8 workgroups per CU
 }
@@ -208,6 +209,8 @@ class Net:
         self.fold_eval_bn = os.environ.get('BPB_FOLD_EVAL_BN', '1') != '0'
         self.dgrad_bn_partials = os.environ.get('BPB_DGRAD_BN', '1') != '0'    # BatchNorm-backward partials from the dgrad epilogue
         self.use_s1w = os.environ.get('BPB_CONV_S1W', '1') != '0'              # 0: strided 3x3 data gradients on the general kernel
+        self.use_conv_c4 = os.environ.get('BPB_CONV_C4', '1') != '0'             # 0: stem forward on the general kernel
+        self.debug_c4 = []
         self.tune_1x1 = os.environ.get('BPB_S1_1X1_TILES', '1') != '0'         # 0: round-3 tile rule for stand-alone 1x1 convolutions
         self.use_wgrad_c4 = os.environ.get('BPB_WGRAD_C4', '1') != '0'         # 0: stem weight gradients on the first-generation kernel
         self.eval_residual_epilogue = os.environ.get('BPB_EVAL_RES', '1') != '0'   # eval plan: residual adds in the conv epilogue
@@ -704,10 +707,28 @@ class Net:
                 x, y = cv.x, cv.y
                 stats = [] if cv.bn is not None else None
                 prob = None
-                if self.use_s1 and cv.is_s1_fwd and (cv.stride == 1 or os.environ.get('BPB_S1_STRIDE2', '1') != '0'):
+                # the stem (3 input channels = the NHWC4 image, 64 output channels, stride 2): csrc/conv_c4.hip, K = the real channels
+                c4 = (self.use_conv_c4 and x.C == 4 and cv.stride == 2 and cv.R == cv.S and cv.R in (3, 7) and cv.pad == cv.R // 2 and
+                      y.C == 64 and cv.bias is None)
+                if c4:
+                    n_mt = x.N * _cdiv(y.H, 8) * _cdiv(y.W, 16)                  # 8 x 16-pixel output tiles
+                    c4_blocks = _cdiv(n_mt, _cdiv(n_mt, TUNE['conv_c4_blocks']))   # workgroups: every one gets a tile, statistics: one row each
+                    c4_stats = torch.empty(c4_blocks * 2 * 64, device=dev, dtype=torch.float64) if cv.bn is not None else None
+
+                    def c4_rec(w_, y_, bias_, stats_, relu_):
+                        return self._single(nv.OP_CONV_C4, 'conv_fwd bpb_conv_c4_kernel<%d>' % cv.R, 2.0 * y.N * y.H * y.W * cv.R * cv.S * 3 * 64,
+                                            4.0 * (x.buf.numel() + y.buf.numel()), ints=(x.N, x.H, x.W, cv.R, 64, relu_, c4_blocks),
+                                            ptrs=(x.buf, w_, y_, bias_, stats_))
+                    self.debug_c4.append((cv, c4_blocks))
+                    if cv.bn is None:
+                        for pl in both:
+                            pl.add(c4_rec(cv.wf, y.buf, None, None, 0))
+                        continue
+                    stats.append(c4_stats)
+                elif self.use_s1 and cv.is_s1_fwd and (cv.stride == 1 or os.environ.get('BPB_S1_STRIDE2', '1') != '0'):
                     prob = self.s1_problem(x.buf, (x.N, x.H, x.W), cv.wf, y.buf, x.C, y.C, cv.R, bias=cv.bias, stats=stats,
                                            in_region=region != 0, stride=cv.stride, nbranch=self._region_slots().get(region, 0))
-                if prob is None:
+                if prob is None and not c4:
                     prob = self.conv_problem(x.buf, (x.N, x.H, x.W), cv.wf, y.buf, (y.H, y.W), y.H, y.W, (1, 1, 0, 0),
                                              cv.stride, (-cv.pad, -cv.pad), (cv.R, cv.S, 0, 1, 0, 1, 0, cv.S, 1), x.C, y.C,
                                              bias=cv.bias, stats=stats)
@@ -719,9 +740,22 @@ class Net:
                     cv.stats_buf = stats[0]
                     count = float(y.N * y.H * y.W)
                     # eval plan: same launch without the statistics epilogue, affine from the running statistics
-                    prob_eval = type(prob).from_buffer_copy(prob)
-                    prob_eval.stats = None
-                    if cv.folded:              # y = conv(x; w * scale) + shift [, ReLU, written straight into the fuse output]
+                    if c4:
+                        ev = dict(w=cv.wf, y=y.buf, bias=None, relu=0)
+                        if cv.folded:
+                            ev.update(w=cv.wf_eval, bias=bn.shift)
+                            sink = eval_sink.get(id(cv))
+                            if sink is not None and sink[2] is not None:
+                                eval_skip.discard(sink[3])       # (no residual operand here: keep the fuse launch)
+                                sink = None
+                            if sink is not None:
+                                ev.update(y=sink[0].buf, relu=1 if sink[1] else 0)
+                        self.fwd_train.add(c4_rec(cv.wf, y.buf, None, c4_stats, 0))
+                        self.fwd_eval.add(c4_rec(ev['w'], ev['y'], ev['bias'], None, ev['relu']))
+                    prob_eval = type(prob).from_buffer_copy(prob) if not c4 else None
+                    if not c4:
+                        prob_eval.stats = None
+                    if cv.folded and not c4:   # y = conv(x; w * scale) + shift [, ReLU, written straight into the fuse output]
                         prob_eval.w = cv.wf_eval.data_ptr()
                         prob_eval.bias = bn.shift.data_ptr()
                         sink = eval_sink.get(id(cv))
@@ -733,10 +767,11 @@ class Net:
                             prob_eval.relu = 1 if sink[1] else 0
                             if sink[2] is not None:
                                 prob_eval.res = sink[2].buf.data_ptr()
-                    self.fwd_train.add(self._conv_rec(prob, 'conv_fwd'))
-                    self.fwd_eval.add(self._conv_rec(prob_eval, 'conv_fwd'))
+                    if not c4:
+                        self.fwd_train.add(self._conv_rec(prob, 'conv_fwd'))
+                        self.fwd_eval.add(self._conv_rec(prob_eval, 'conv_fwd'))
                     fd = BnFinDesc()
-                    fd.partials, fd.nparts, fd.C, fd.count = cv.stats_buf.data_ptr(), prob.n_mtiles, y.C, count
+                    fd.partials, fd.nparts, fd.C, fd.count = cv.stats_buf.data_ptr(), (c4_blocks if c4 else prob.n_mtiles), y.C, count
                     fd.gamma, fd.beta = bn.weight.data_ptr(), bn.bias.data_ptr()
                     fd.scale, fd.shift, fd.mean, fd.invstd = (bn.scale.data_ptr(), bn.shift.data_ptr(), bn.mean.data_ptr(),
                                                               bn.invstd.data_ptr())

@@ -361,6 +361,7 @@ typedef enum BpbOpKind {
     BPB_OP_WGRAD1X1 = 30,          /* p0 device BpbWgrad1x1Prob[], p1 host copy, i0 nprobs */
     BPB_OP_CONV_S1W = 31,          /* p0 device BpbConvS1wProb[], p1 host copy, i0 nprobs */
     BPB_OP_WGRAD_C4 = 32,          /* p0 device BpbWgradProb[], p1 host copy, i0 nprobs */
+    BPB_OP_CONV_C4 = 33,           /* p0 x, p1 w, p2 y, p3 bias, p4 stats, i0 N, i1 Hi, i2 Wi, i3 R, i4 Cout, i5 relu, i6 nblk */
 } BpbOpKind;
 
 // generic op record; slot meaning per kind is documented next to each case; i[10] = stream slot (0 = the caller's stream, 1..3 = branch streams,
@@ -405,6 +406,13 @@ int bpb_conv_s1w(const BpbConvS1wProb* d_probs, const BpbConvS1wProb* h_probs, i
 int bpb_conv_wgrad(const BpbWgradProb* d_probs, const BpbWgradProb* h_probs, int nprobs, hipStream_t stream);
 int bpb_wgrad_reduce(const float* ws, float* dw, int nsplit, int T, int Cin, int Cin_real, int Cout, int accumulate,
                      hipStream_t stream);
+/* Stem convolution forward (csrc/conv_c4.hip): y[N, H, W, 64] = conv_RxR(x[N, Hi, Wi, 4 (3 real channels)]), R in {3, 7}, stride 2,
+ * padding R / 2 -- hrnet.py:319-320, resnet.py:211-213.  `w`: forward packing of bpb_pack_weights; `stats` (training): nblk rows of
+ * per-channel (sum, sum of squares) in fp64, one per workgroup; `bias` / `relu`: the eval plan's folded BatchNorm.  nblk workgroups
+ * share the 8 x 16-pixel output tiles evenly (ceil(tiles / ceil(tiles / nblk)) must equal nblk). */
+int bpb_conv_c4_init(void);
+int bpb_conv_c4(const float* x, const float* w, float* y, const float* bias, double* stats, int N, int Hi, int Wi, int R, int Cout,
+                int relu, int nblk, hipStream_t stream);
 int bpb_pack_weights(const BpbPackProb* d_probs, int nprobs, int total_blocks, hipStream_t stream);
 
 /* ---- BatchNorm2d + residual / fuse sums + nearest upsample + ReLU --------------------------------------------------

@@ -76,6 +76,73 @@ def run_pack(w, cin_pad, ib, scale=None, dgrad=True):
     return wf, wd, nblk
 
 
+def run_conv_c4(x, wf, r, nblk, bias=None, relu=False):
+    """bpb_conv_c4_kernel<R> (csrc/conv_c4.hip): x [N,Hi,Wi,4], wf = forward packing [T][1][64][4]; 8 x 16-pixel output tiles, the
+    staged (14 + R) x (30 + R) input pixels as one 16-byte slot each, MFMA step = (tap pair, real channel), A addresses =
+    base[class(step)] + constant(step) exactly as the kernel forms them.  Returns (y [N,H,W,64], stats [nblk,2,64])."""
+    n_img, hi, wi, _ = x.shape
+    t, pad, th_n, tw_n = r * r, r // 2, 8, 16
+    hh, hw = 2 * th_n + r - 2, 2 * tw_n + r - 2
+    ks = ((t + 1) // 2) * 3
+    d_row = (hw - (r - 1)) * 16
+    h, w = (hi - 1) // 2 + 1, (wi - 1) // 2 + 1
+    tiles_a, tiles_b = -(-h // th_n), -(-w // tw_n)
+    n_mtiles = n_img * tiles_a * tiles_b
+    per = -(-n_mtiles // nblk)
+    assert -(-n_mtiles // per) == nblk
+    wl = np.zeros((2 * ks, 64), dtype=np.float64)       # row 2 * step + lane half = W[tap 2j + half][ci i], step = 3 j + i
+    wfr = wf.reshape(t, 64, 4)
+    for row in range(2 * ks):
+        st = row >> 1
+        tap, ci = 2 * (st // 3) + (row & 1), st % 3
+        if tap < t:
+            wl[row] = wfr[tap, :, ci]
+    m = np.arange(128)
+    pixbase = (((m >> 4) * 2) * hw + (m & 15) * 2) * 16
+    delta = [16, d_row, 0]
+
+    def cls_imm(s_):
+        t0, ci = 2 * (s_ // 3), s_ % 3
+        c = 2 if t0 + 1 >= t else 0 if (t0 + 1) % r != 0 else 1
+        return c, ((t0 // r) * hw + t0 % r) * 16 + ci * 4
+
+    y = np.full((n_img, h, w, 64), np.nan)
+    stats = np.zeros((nblk, 2, 64))
+    for bid in range(nblk):
+        for mtile in range(bid * per, min(n_mtiles, (bid + 1) * per)):
+            tb, t2 = mtile % tiles_b, mtile // tiles_b
+            n, ta = t2 // tiles_a, t2 % tiles_a
+            a0, b0 = ta * th_n, tb * tw_n
+            halo = np.zeros((hh, hw, 4))
+            for hr in range(hh):
+                ih = a0 * 2 + hr - pad
+                if not 0 <= ih < hi:
+                    continue
+                lo, hi_ = max(0, pad - b0 * 2), min(hw, wi + pad - b0 * 2)
+                if hi_ > lo:
+                    halo[hr, lo:hi_] = x[n, ih, b0 * 2 + lo - pad:b0 * 2 + hi_ - pad]
+            flat = halo.reshape(-1)
+            acc = np.zeros((128, 64))
+            for s_ in range(ks):
+                c, imm = cls_imm(s_)
+                for half in range(2):
+                    addr = pixbase + half * delta[c] + imm
+                    assert addr.max() + 4 <= flat.size * 4 and addr.min() >= 0
+                    acc += np.outer(flat[addr // 4], wl[2 * s_ + half])
+            if bias is not None:
+                acc = acc + bias[None, :]
+            if relu:
+                acc = np.maximum(acc, 0.0)
+            for mm in range(128):
+                a, b = a0 + (mm >> 4), b0 + (mm & 15)
+                if a < h and b < w:
+                    assert np.isnan(y[n, a, b, 0])
+                    y[n, a, b] = acc[mm]
+                    stats[bid, 0] += acc[mm]
+                    stats[bid, 1] += acc[mm] ** 2
+    return y, stats
+
+
 def run_conv(p, x, wpk, y, bias=None):
     """p: object with the ConvProb fields; x [N,Hi,Wi,Cin], wpk flat packed weights, y [N,Ho,Wo,Cout] (in/out)."""
     ti_n, th_n, tw_n = 1 << p.lTI, 1 << p.lTH, 1 << p.lTW

@@ -35,6 +35,26 @@ def main(name, threads):
     if control == 'channels_last':       # other oneDNN kernels: another summation order inside the convolutions
         model = model.to(memory_format=torch.channels_last)
         imgs = imgs.contiguous(memory_format=torch.channels_last)
+    if control.startswith('stem'):
+        # ONLY the stem convolution (3 input channels) changes: 'stem64' = its output computed in fp64 and rounded to fp32 (more
+        # accurate than any fp32 summation order), 'stem_taps' = the fp32 sum of one convolution per filter row (another order).
+        # Everything behind it is the reference's own fp32 run: what a different -- or a perfect -- stem does to the gradients.
+        import torch.nn.functional as F
+        stem = [m_ for m_ in model.modules() if isinstance(m_, torch.nn.Conv2d) and m_.in_channels == 3][0]
+
+        def hook(mod, inp, out_):
+            x_ = inp[0]
+            if control == 'stem64':
+                return F.conv2d(x_.double(), mod.weight.double(), None, mod.stride, mod.padding).float()
+            r_ = mod.weight.shape[2]
+            xp = F.pad(x_, (mod.padding[1], mod.padding[1], mod.padding[0], mod.padding[0]))
+            acc = None
+            for i_ in reversed(range(r_)):
+                rows = xp[:, :, i_:xp.shape[2] - (r_ - 1 - i_)]
+                t_ = F.conv2d(rows, mod.weight[:, :, i_:i_ + 1], None, mod.stride, 0)
+                acc = t_ if acc is None else acc + t_
+            return acc
+        stem.register_forward_hook(hook)
     out = model(imgs, external_parts_masks=masks)
     store = {}
     G.dump_outputs(store, 'x', out)

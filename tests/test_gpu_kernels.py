@@ -80,6 +80,43 @@ def test_weight_packing_equals_the_index_definition(shape):
     assert np.array_equal(outs[1][0].cpu().numpy(), emu.pack_fwd(wn * scale.numpy()[:, None, None, None], cin_pad))
 
 
+@pytest.mark.parametrize('r, n, hi, wi, nblk', [(3, 3, 40, 24, 5), (7, 2, 36, 52, 4), (7, 4, 64, 32, 16), (3, 2, 256, 128, 512), (7, 2, 256, 128, 512)])
+def test_stem_forward_kernel(r, n, hi, wi, nblk):
+    """bpb_conv_c4 (3 -> 64 channels, 3x3 / 7x7, stride 2) against F.conv2d in fp64: ragged tiles, several tiles per workgroup, the
+    per-workgroup BatchNorm partial rows, the eval epilogue (bias + ReLU); the padding channel of the NHWC4 image holds garbage."""
+    g = torch.Generator().manual_seed(r * 1000 + hi)
+    x = torch.randn(n, 3, hi, wi, generator=g)
+    w = torch.randn(64, 3, r, r, generator=g) * 0.2
+    bias = torch.randn(64, generator=g)
+    ref = F.conv2d(x.double(), w.double(), stride=2, padding=r // 2)
+    h, wo = ref.shape[2], ref.shape[3]
+    x4 = torch.cat([nhwc(x), torch.randn(n, hi, wi, 1, generator=g)], dim=3).contiguous().to(DEV)
+    import conv_emulator as emu
+    wf = torch.from_numpy(emu.pack_fwd(w.numpy(), 4)).to(DEV)
+    n_mtiles = n * -(-h // 8) * -(-wo // 16)
+    nblk = -(-n_mtiles // -(-n_mtiles // min(nblk, n_mtiles)))
+    y = torch.full((n, h, wo, 64), float('nan'), device=DEV)
+    stats = torch.full((nblk, 2, 64), float('nan'), device=DEV, dtype=torch.float64)
+    nv.call('bpb_conv_c4', x4.data_ptr(), wf.data_ptr(), y.data_ptr(), None, stats.data_ptr(), n, hi, wi, r, 64, 0, nblk, nv.stream())
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    assert float((nchw(y.cpu()).double() - ref).abs().max()) <= 2e-5 * scale
+    st = stats.cpu().sum(0)
+    assert torch.allclose(st[0], ref.sum((0, 2, 3)), rtol=1e-5, atol=1e-4 * scale)
+    assert torch.allclose(st[1], (ref ** 2).sum((0, 2, 3)), rtol=1e-5)
+    y2 = torch.full((n, h, wo, 64), float('nan'), device=DEV)
+    bd = bias.to(DEV)
+    nv.call('bpb_conv_c4', x4.data_ptr(), wf.data_ptr(), y2.data_ptr(), bd.data_ptr(), None, n, hi, wi, r, 64, 1, nblk, nv.stream())
+    torch.cuda.synchronize()
+    ref2 = torch.relu(ref + bias.double()[None, :, None, None])
+    assert float((nchw(y2.cpu()).double() - ref2).abs().max()) <= 2e-5 * scale
+    # bit-identical from run to run and for any number of workgroups (a tile's sums do not depend on who computes it)
+    y3 = torch.empty_like(y)
+    nv.call('bpb_conv_c4', x4.data_ptr(), wf.data_ptr(), y3.data_ptr(), None, None, n, hi, wi, r, 64, 0, n_mtiles, nv.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(y, y3)
+
+
 def test_mfma_f32_layout_via_identity_conv():
     """A = I check with an asymmetric B (guide rule 16): 1x1 conv with identity weights must copy, with a
     permutation matrix must permute channels, nothing transposed."""
@@ -158,6 +195,7 @@ def test_conv_forward_backward(case, s1, tile=None, tpb=None, dma=True, ck=None)
     net.use_s1 = s1
     net.use_wgrad16 = s1          # both generations of the weight-gradient kernels are covered by the s1 switch
     net.use_wgrad1x1 = s1
+    net.use_conv_c4 = s1
     net.force_tile = tile
     net.force_tpb = tpb
     net.use_dma = dma
@@ -177,7 +215,10 @@ def test_conv_forward_backward(case, s1, tile=None, tpb=None, dma=True, ck=None)
     out = net.fuse([(node, 0)], relu=False)
     net.finalize(train_backward=True)
     lean = stride in (1, 2) and k in (1, 3) and pad == k // 2 and cin % 8 == 0 and cout % 8 == 0
-    if ck is None and tile is None:   # (a forced tile / chunk that does not fit the 12-piece DMA budget falls back to the general kernel)
+    stem = cin == 3 and cout == 64 and stride == 2 and k in (3, 7) and pad == k // 2
+    if stem:                          # csrc/conv_c4.hip with the lean family, the general kernel otherwise
+        assert len(net.debug_c4) == (1 if s1 else 0) and len(net.debug_convs) == (0 if s1 else 1), 'kernel selection (stem)'
+    elif ck is None and tile is None:   # (a forced tile / chunk that does not fit the 12-piece DMA budget falls back to the general kernel)
         assert isinstance(net.debug_convs[0][0], nv.ConvS1Prob) == (s1 and lean), 'kernel selection'
     net.run(net.plan_train)
     torch.cuda.synchronize()

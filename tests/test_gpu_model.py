@@ -249,7 +249,10 @@ def test_model_matches_reference_golden(name, lowres, golden_dir):
         # 10-46 % of the hrnet_w8 parameters and 0-1 % of the ResNet-50 ones outside the per-parameter contract bound, <= 0.7 %
         # outside the wide bound, median error 0.8-7.2x the reference's own fp32 noise).  Bounded in aggregate, never by the
         # cosine alone: direction relative to the reference's own fp32 run, typical error relative to its noise, the wide bound
-        # for 99 % of the parameters.
+        # for 99 % of the parameters.  (Round 4, tests/golden/noise_control.py CONTROL=stem_taps: the REFERENCE with nothing but the
+        # summation order of its stem convolution changed lands at median err / noise 9.4 with 53 of 985 parameters outside the wide
+        # bound on hrw8_k5 -- and at 1.2 / none on the well-conditioned hrw16 fixture; noise_control_r04.txt.  These bounds hold
+        # because csrc/conv_c4.hip keeps the summation order of the kernel it replaced, not because the order is better than another.)
         assert 1.0 - cosine <= max(1e-4, 2.0 * (1.0 - cosine_ref)), (cosine, cosine_ref)
         assert med <= 10.0, med
         assert len(bad) <= 0.01 * len(digests), (len(bad), len(digests), bad[:6])

@@ -172,6 +172,29 @@ def test_weight_packing_tiles_write_every_packed_element_once(shape):
     assert np.array_equal(wfs, emu.pack_fwd(w * scale[:, None, None, None], cin_pad))
 
 
+@pytest.mark.parametrize('r, hi, wi, nblk', [(3, 20, 36, 8), (7, 20, 36, 3), (7, 33, 17, 6), (3, 16, 32, 2)])
+def test_stem_forward_kernel_index_algebra(r, hi, wi, nblk):
+    """csrc/conv_c4.hip on the emulator: the K = (tap, real channel) matrix, the three k -> k + 1 address classes (next channel, next
+    tap, next filter row) + the zero row of an odd K, ragged 8 x 16 tiles, workgroups walking tile ranges with one statistics row
+    each -- against F.conv2d in fp64."""
+    rng = np.random.default_rng(r * 100 + hi)
+    n = 2
+    x = rng.standard_normal((n, hi, wi, 4))
+    x[..., 3] = rng.standard_normal((n, hi, wi))          # garbage in the padding channel must not matter
+    w = rng.standard_normal((64, 3, r, r))
+    wf = emu.pack_fwd(w, 4)
+    n_mtiles = n * -(-((hi - 1) // 2 + 1) // 8) * -(-((wi - 1) // 2 + 1) // 16)
+    nblk = -(-n_mtiles // -(-n_mtiles // nblk))
+    y, stats = emu.run_conv_c4(x, wf, r, nblk)
+    ref = F.conv2d(torch.from_numpy(x[..., :3]).permute(0, 3, 1, 2), torch.from_numpy(w), stride=2, padding=r // 2).permute(0, 2, 3, 1).numpy()
+    assert y.shape == ref.shape and not np.isnan(y).any()
+    assert np.abs(y - ref).max() < 1e-10
+    assert np.allclose(stats[:, 0].sum(0), ref.sum((0, 1, 2))) and np.allclose(stats[:, 1].sum(0), (ref ** 2).sum((0, 1, 2)))
+    bias = rng.standard_normal(64)
+    y2, _ = emu.run_conv_c4(x, wf, r, nblk, bias=bias, relu=True)
+    assert np.abs(y2 - np.maximum(ref + bias, 0)).max() < 1e-10
+
+
 def test_standalone_1x1_convolutions_take_128_pixel_tiles_where_every_cu_still_gets_a_workgroup(monkeypatch):
     """Plan-time tile rule of 1x1 launches that stand alone (ResNet-50 layers 2-4, profiles/r04_s1_sweep_1x1.txt): 128 pixels x 64
     channels with 32-channel chunks where the convolution narrows (K >= 256), 128 x 128 where it widens by 4; the round-3 tile at
