@@ -145,6 +145,9 @@ static int run_one(const BpbPlanOp& o, int k, hipStream_t stream)
                 rc = bpb_conv_c4((const float*)o.p[0], (const float*)o.p[1], (float*)o.p[2], (const float*)o.p[3], (double*)o.p[4], o.i[0], o.i[1],
                                  o.i[2], o.i[3], o.i[4], o.i[5], o.i[6], stream);
                 break;
+            case BPB_OP_SCATTER_S2:   // p0 src, p1 dst, i0 N, i1 A, i2 B, i3 H, i4 W, i5 C, i6 accumulate
+                rc = bpb_scatter_stride2((const float*)o.p[0], (float*)o.p[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], o.i[6], stream);
+                break;
             case BPB_OP_WGRAD_C4:
                 rc = bpb_conv_wgrad_c4((const BpbWgradProb*)o.p[0], (const BpbWgradProb*)o.p[1], o.i[0], stream);
                 break;

@@ -18,6 +18,41 @@ __global__ __launch_bounds__(256) void bpb_nchw_to_nhwc4_kernel(const float* __r
     }
 }
 
+// Zero insertion: dst[n][2a][2b][:] (+)= src[n][a][b][:], every other pixel of dst 0 (or untouched when accumulating).  The data
+// gradient of a 1x1 stride-2 convolution (resnet.py:119-127 downsample paths) is the 1x1 stride-1 data gradient on dy -- the lean
+// kernel, into a compact [N][A][B][C] buffer -- spread over the even pixels of dx by this pass.
+__global__ __launch_bounds__(256) void bpb_scatter_stride2_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int A, int B,
+                                                                  int H, int W, int c4, int accumulate)
+{
+    if (accumulate) {       // only the even pixels change
+        const long total = (long)N * A * B * c4;
+        for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+            const int cq = (int)(i % c4);
+            long q = i / c4;
+            const int b = (int)(q % B);
+            q /= B;
+            const int a = (int)(q % A);
+            const long n = q / A;
+            float* o = dst + (((n * H + 2 * a) * W + 2 * b) * (long)c4 + cq) * 4;
+            const f32x4 v = *(const f32x4*)(src + i * 4), old = *(const f32x4*)o;
+            *(f32x4*)o = v + old;
+        }
+        return;
+    }
+    const long total = (long)N * H * W * c4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+        const int cq = (int)(i % c4);
+        long q = i / c4;
+        const int w = (int)(q % W);
+        q /= W;
+        const int h = (int)(q % H);
+        const long n = q / H;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (!((h | w) & 1)) v = *(const f32x4*)(src + (((n * A + (h >> 1)) * B + (w >> 1)) * (long)c4 + cq) * 4);
+        *(f32x4*)(dst + i * 4) = v;
+    }
+}
+
 // NHWC -> NCHW (used for returning pixel-classifier logits and for tests)
 __global__ __launch_bounds__(256) void bpb_nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int N,
                                                                int C, int HW)
@@ -434,6 +469,15 @@ int bpb_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, hipS
 {
     BPB_REQUIRE(C >= 1 && C <= 4, "bpb_nchw_to_nhwc4: C=%d", C);
     hipLaunchKernelGGL(bpb_nchw_to_nhwc4_kernel, dim3(ew_grid((long)N * H * W)), dim3(256), 0, stream, x, y, N, C, H * W);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_scatter_stride2(const float* src, float* dst, int N, int A, int B, int H, int W, int C, int accumulate, hipStream_t stream)
+{
+    BPB_REQUIRE(C % 4 == 0 && N >= 1 && A == (H + 1) / 2 && B == (W + 1) / 2, "bpb_scatter_stride2: C=%d, %dx%d -> %dx%d", C, A, B, H, W);
+    const long total = accumulate ? (long)N * A * B * (C / 4) : (long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(bpb_scatter_stride2_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, src, dst, N, A, B, H, W, C / 4, accumulate);
     BPB_LAUNCH_OK();
     return 0;
 }

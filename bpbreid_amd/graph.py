@@ -209,6 +209,7 @@ class Net:
         self.fold_eval_bn = os.environ.get('BPB_FOLD_EVAL_BN', '1') != '0'
         self.dgrad_bn_partials = os.environ.get('BPB_DGRAD_BN', '1') != '0'    # BatchNorm-backward partials from the dgrad epilogue
         self.use_s1w = os.environ.get('BPB_CONV_S1W', '1') != '0'              # 0: strided 3x3 data gradients on the general kernel
+        self.use_s1_1x1s2 = os.environ.get('BPB_S1_1X1_STRIDE2', '1') != '0'    # 0: data gradient of 1x1 stride-2 convolutions as parity classes of the general kernel
         self.use_conv_c4 = os.environ.get('BPB_CONV_C4', '1') != '0'             # 0: stem forward on the general kernel
         self.debug_c4 = []
         self.tune_1x1 = os.environ.get('BPB_S1_1X1_TILES', '1') != '0'         # 0: round-3 tile rule for stand-alone 1x1 convolutions
@@ -1444,6 +1445,20 @@ class Net:
                 bwd.add(Rec(nv.OP_CONV_S1W, 'conv_dgrad bpb_conv_s1w_kernel<%d>' % (prob.CK // 8), 2.0 * y.N * y.H * y.W * 9 * cout * x.C,
                             4.0 * (x.buf.numel() + y.buf.numel()), desc=prob, key=('s1w', prob.CK), blocks=prob.n_mtiles * prob.n_ntiles,
                             work=9 * prob.Cin))
+                return
+        if (self.use_s1 and self.use_s1_1x1s2 and st == 2 and r == 1 and s == 1 and pad == 0 and cout % 8 == 0 and x.C % 8 == 0
+                and y.H == (x.H + 1) // 2 and y.W == (x.W + 1) // 2):
+            # 1x1 stride 2 (ResNet downsample paths): only the even pixels of dx receive anything, and what they receive is the
+            # stride-1 1x1 data gradient on dy -- the lean kernel into a compact buffer, then one zero-insertion pass over dx
+            # (the general kernel ran four parity classes, three of them empty tap sets that only write zeros: 40 TFLOP/s)
+            tmp = torch.empty(y.N * y.H * y.W * x.C, device=self.device, dtype=torch.float32)
+            self.keep.append(tmp)
+            prob = self.s1_problem(gy, (y.N, y.H, y.W), cv.wd, tmp, cout, x.C, 1, accumulate=0, wflip=1, in_region=self._bwd_region != 0,
+                                   nbranch=self._region_slots().get(self._bwd_region, 0))
+            if prob is not None:
+                bwd.add(self._conv_rec(prob, 'conv_dgrad'))
+                bwd.add(self._single(nv.OP_SCATTER_S2, 'scatter_stride2', 0, 4.0 * (tmp.numel() * (2 if acc else 1) + (tmp.numel() if acc else x.buf.numel())),
+                                     ints=(y.N, y.H, y.W, x.H, x.W, x.C, acc), ptrs=(tmp, gx)))
                 return
         for ph in range(st):
             for pw in range(st):

@@ -362,6 +362,7 @@ typedef enum BpbOpKind {
     BPB_OP_CONV_S1W = 31,          /* p0 device BpbConvS1wProb[], p1 host copy, i0 nprobs */
     BPB_OP_WGRAD_C4 = 32,          /* p0 device BpbWgradProb[], p1 host copy, i0 nprobs */
     BPB_OP_CONV_C4 = 33,           /* p0 x, p1 w, p2 y, p3 bias, p4 stats, i0 N, i1 Hi, i2 Wi, i3 R, i4 Cout, i5 relu, i6 nblk */
+    BPB_OP_SCATTER_S2 = 34,        /* p0 src, p1 dst, i0 N, i1 A, i2 B, i3 H, i4 W, i5 C, i6 accumulate */
 } BpbOpKind;
 
 // generic op record; slot meaning per kind is documented next to each case; i[10] = stream slot (0 = the caller's stream, 1..3 = branch streams,
@@ -442,6 +443,9 @@ int bpb_bn_bwd_finalize_multi(const BpbBnBwdFinDesc* d_descs, const BpbBnBwdFinD
  * NCHW boundary of engine/image/part_based_engine.py:347-351; resnet.py:217,346 (max pool);
  * hrnet.py:568-573 (F.interpolate bilinear align_corners x3 + torch.cat). */
 int bpb_nchw_to_nhwc4(const float* x, float* y, int N, int C, int H, int W, hipStream_t stream);
+/* dst[N,H,W,C] at the even pixels (+)= src[N,(H+1)/2,(W+1)/2,C], zero elsewhere (untouched when accumulating): the second half of
+   the data gradient of a 1x1 stride-2 convolution (resnet.py:119-127), whose first half is the stride-1 lean kernel on dy */
+int bpb_scatter_stride2(const float* src, float* dst, int N, int A, int B, int H, int W, int C, int accumulate, hipStream_t stream);
 int bpb_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, hipStream_t stream);
 int bpb_maxpool3x3s2_fwd(const float* x, float* y, unsigned char* idx, int N, int H, int W, int C, hipStream_t stream);
 int bpb_maxpool3x3s2_bwd(const float* dy, const unsigned char* idx, float* dx, int N, int H, int W, int C, int accumulate,

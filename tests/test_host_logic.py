@@ -275,6 +275,17 @@ def test_conv_descriptors_forward_dgrad_wgrad(case):
         if isinstance(dprobs[0], nv.ConvS1wProb):
             assert len(dprobs) == 1 and (dprobs[0].A, dprobs[0].B) == ((h + 1) // 2, (w + 1) // 2)
         first = True
+        lean_1x1_s2 = stride == 2 and k == 1 and pad == 0 and cin % 8 == 0 and cout % 8 == 0
+        if lean_1x1_s2:
+            # 1x1 stride 2: the stride-1 lean problem on dy into a compact buffer + the zero-insertion pass (OP_SCATTER_S2) over dx
+            assert len(dprobs) == 1 and isinstance(dprobs[0], nv.ConvS1Prob) and (dprobs[0].H, dprobs[0].W, dprobs[0].S) == (node.y.H, node.y.W, 1)
+            sc = [r for r in net.bwd if r.kind == nv.OP_SCATTER_S2]
+            assert len(sc) == 1 and list(sc[0].op.i[:7]) == [n, node.y.H, node.y.W, h, w, cin, 0] and sc[0].op.p[0] == dprobs[0].y
+            tmp = np.zeros((n, node.y.H, node.y.W, cin))
+            run(dprobs[0], gy.numpy(), emu.pack_dgrad(wt.numpy(), cpad), tmp)
+            gx[:] = 0
+            gx[:, ::2, ::2] = tmp
+            dprobs = []
         for dp in dprobs:
             assert dp.accumulate == 0      # single consumer in this mini graph
             if first:
