@@ -76,6 +76,45 @@ def run_pack(w, cin_pad, ib, scale=None, dgrad=True):
     return wf, wd, nblk
 
 
+def run_argsort_rows(dist, tpb=1024):
+    """bpb_argsort_rows_kernel (csrc/argsort_gpu.hip), one row per workgroup: order-preserving key bits, four 8-bit LSD passes, each a
+    digit histogram + exclusive scan + STABLE scatter in chunks of `tpb` consecutive elements -- rank inside the wave from the lanes
+    with the same digit (the kernel's eight ballots), waves ordered through the [wave][digit] count table, running digit bases."""
+    q, g = dist.shape
+    out = np.empty((q, g), dtype=np.int32)
+    waves = tpb // 64
+    for row in range(q):
+        u = dist[row].astype(np.float32).view(np.uint32).astype(np.uint64)
+        keys = (u ^ np.where(u >> 31, np.uint64(0xFFFFFFFF), np.uint64(0x80000000))).astype(np.uint64)
+        vals = np.arange(g, dtype=np.int64)
+        for p in range(4):
+            dig = ((keys >> np.uint64(8 * p)) & np.uint64(255)).astype(np.int64)
+            hist = np.bincount(dig, minlength=256)
+            base = np.cumsum(hist) - hist                      # exclusive scan
+            nk, nv = np.empty_like(keys), np.empty_like(vals)
+            for c0 in range(0, g, tpb):
+                n = min(tpb, g - c0)
+                d = dig[c0:c0 + n]
+                wcnt = np.zeros((waves, 256), dtype=np.int64)
+                rank = np.zeros(n, dtype=np.int64)
+                for w in range(-(-n // 64)):
+                    lanes = d[w * 64:(w + 1) * 64]
+                    for lane, dl in enumerate(lanes):
+                        peers = lanes == dl                     # (invalid lanes of the last wave are excluded by the first ballot)
+                        rank[w * 64 + lane] = int(peers[:lane].sum())
+                        if rank[w * 64 + lane] == 0:
+                            wcnt[w, dl] = int(peers.sum())
+                wpre = np.cumsum(wcnt, axis=0) - wcnt           # exclusive prefix over the waves, per digit
+                tot = wcnt.sum(0)
+                pos = base[d] + wpre[np.arange(n) // 64, d] + rank
+                assert len(set(pos.tolist())) == n
+                nk[pos], nv[pos] = keys[c0:c0 + n], vals[c0:c0 + n]
+                base = base + tot
+            keys, vals = nk, nv
+        out[row] = vals
+    return out
+
+
 def run_conv_c4(x, wf, r, nblk, bias=None, relu=False):
     """bpb_conv_c4_kernel<R> (csrc/conv_c4.hip): x [N,Hi,Wi,4], wf = forward packing [T][1][64][4]; 8 x 16-pixel output tiles, the
     staged (14 + R) x (30 + R) input pixels as one 16-byte slot each, MFMA step = (tap pair, real channel), A addresses =

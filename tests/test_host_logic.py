@@ -195,6 +195,20 @@ def test_stem_forward_kernel_index_algebra(r, hi, wi, nblk):
     assert np.abs(y2 - np.maximum(ref + bias, 0)).max() < 1e-10
 
 
+def test_row_argsort_algorithm_is_the_stable_argsort():
+    """csrc/argsort_gpu.hip on the emulator: key transform (negative values, zeros), 8-bit LSD passes, ballot-style ranks inside a wave,
+    the [wave][digit] table across the waves of a chunk, ragged last chunk -- equal to np.argsort(kind='stable') incl. heavy ties."""
+    rng = np.random.default_rng(5)
+    for q, g, quant in ((3, 1, 0), (2, 63, 0), (2, 200, 4), (2, 1500, 0), (1, 2600, 8)):
+        d = rng.standard_normal((q, g)).astype(np.float32) * 3
+        if quant:
+            d = np.floor(d * quant) / quant
+            d[:, ::5] = 7.5
+        d[d == 0] = 0.0                                          # (-0.0 would sort before +0.0: never produced by the distance path)
+        got = emu.run_argsort_rows(d, tpb=256 if g < 1500 else 1024)
+        assert np.array_equal(got, np.argsort(d, axis=1, kind='stable')), (q, g, quant)
+
+
 def test_standalone_1x1_convolutions_take_128_pixel_tiles_where_every_cu_still_gets_a_workgroup(monkeypatch):
     """Plan-time tile rule of 1x1 launches that stand alone (ResNet-50 layers 2-4, profiles/r04_s1_sweep_1x1.txt): 128 pixels x 64
     channels with 32-channel chunks where the convolution narrows (K >= 256), 128 x 128 where it widens by 4; the round-3 tile at
