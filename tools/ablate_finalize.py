@@ -13,10 +13,7 @@ orig = graph.Net._freeze
 
 
 def freeze(self, recs, name=None):
-    kept = [r for r in recs if r.kind not in drop]
-    if hasattr(recs, 'slot'):            # (the plan lists carry the current slot)
-        pass
-    return orig(self, kept, name)
+    return orig(self, [r for r in recs if r.kind not in drop], name)
 
 
 graph.Net._freeze = freeze
