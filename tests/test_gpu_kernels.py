@@ -117,6 +117,26 @@ def test_stem_forward_kernel(r, n, hi, wi, nblk):
     assert torch.equal(y, y3)
 
 
+@pytest.mark.parametrize('n, h, w, c', [(2, 8, 6, 8), (3, 9, 7, 64), (1, 1, 5, 4), (2, 16, 8, 256)])
+def test_zero_insertion_pass_of_the_strided_1x1_data_gradient(n, h, w, c):
+    """bpb_scatter_stride2: dst at the even pixels (+)= src, zero (write mode) or untouched (accumulate mode) elsewhere; odd extents."""
+    g = torch.Generator().manual_seed(n * 100 + h)
+    a, b = (h + 1) // 2, (w + 1) // 2
+    src = torch.randn(n, a, b, c, generator=g)
+    old = torch.randn(n, h, w, c, generator=g)
+    sd = src.to(DEV)
+    dst = torch.full((n, h, w, c), float('nan'), device=DEV)
+    nv.call('bpb_scatter_stride2', sd.data_ptr(), dst.data_ptr(), n, a, b, h, w, c, 0, nv.stream())
+    ref = torch.zeros(n, h, w, c)
+    ref[:, ::2, ::2] = src
+    assert torch.equal(dst.cpu(), ref)
+    dst2 = old.to(DEV)
+    nv.call('bpb_scatter_stride2', sd.data_ptr(), dst2.data_ptr(), n, a, b, h, w, c, 1, nv.stream())
+    ref2 = old.clone()
+    ref2[:, ::2, ::2] += src
+    assert torch.equal(dst2.cpu(), ref2)
+
+
 def test_mfma_f32_layout_via_identity_conv():
     """A = I check with an asymmetric B (guide rule 16): 1x1 conv with identity weights must copy, with a
     permutation matrix must permute channels, nothing transposed."""
