@@ -227,7 +227,10 @@ def test_folded_finalize_plan_structure(monkeypatch):
     base = build()
     monkeypatch.setenv('BPB_FOLD_FINALIZE', '1')
     net = build()
-    kinds = lambda n_, name: [o.kind for o in [n_.plan_train if name == 'train' else n_.plan_eval if name == 'eval' else n_.plan_bwd][0][0]][:[n_.plan_train if name == 'train' else n_.plan_eval if name == 'eval' else n_.plan_bwd][0][1]]
+    def kinds(n_, name):
+        arr, count, _ = {'train': n_.plan_train, 'eval': n_.plan_eval, 'bwd': n_.plan_bwd}[name]
+        return [arr[k].kind for k in range(count)]
+
     assert kinds(net, 'eval') == kinds(base, 'eval') and kinds(net, 'bwd') == kinds(base, 'bwd')
     kt, kb = kinds(net, 'train'), kinds(base, 'train')
     nfold = kt.count(nv.OP_FUSE_FWD_FOLD)
