@@ -20,8 +20,6 @@
 // Lane r adds rows r, r+128, ... (4 independent loads in flight: the rows are L2-resident, the loop is latency-bound), then
 // the 128 lane sums are combined in a FIXED order through LDS (16 groups of 8, then the 16 group sums) -> deterministic.
 // A 32-channel x 32-lane layout took ~10 us per BatchNorm (64 dependent L2 round trips); this one ~3-4 us.
-// (Templated on the channels per workgroup: the folded form below runs 256 threads = 2 channels x the SAME 128 row lanes, i.e. the same
-// additions in the same order for every channel -- bit-identical sums.)
 #define BPB_FIN_LANES (1024 / BPB_FIN_CH)
 template <int FIN_CH_T = BPB_FIN_CH>
 __device__ __forceinline__ bool bpb_fin_column_sums(int blk, double (*red)[BPB_FIN_LANES][FIN_CH_T], const double* __restrict__ partials,
@@ -79,7 +77,7 @@ __device__ __forceinline__ bool bpb_fin_column_sums(int blk, double (*red)[BPB_F
     return true;
 }
 
-template <int FIN_CH_T = BPB_FIN_CH, bool SC1 = false>     // SC1: write-through stores of what other workgroups of THIS launch read
+template <int FIN_CH_T = BPB_FIN_CH>
 __device__ __forceinline__ void bpb_bn_finalize_body(int blk, double (*red)[BPB_FIN_LANES][FIN_CH_T], const double* __restrict__ partials,
                                                      int nparts, int C, double count, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, float momentum,
@@ -96,13 +94,8 @@ __device__ __forceinline__ void bpb_bn_finalize_body(int blk, double (*red)[BPB_
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
     const float sc = g * invstd;
-    if (SC1) {
-        __hip_atomic_store(scale + c, sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(shift + c, b - (float)mean * sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        scale[c] = sc;
-        shift[c] = b - (float)mean * sc;
-    }
+    scale[c] = sc;
+    shift[c] = b - (float)mean * sc;
     mean_out[c] = (float)mean;
     invstd_out[c] = invstd;
     if (running_mean) {
@@ -244,8 +237,7 @@ __device__ __forceinline__ unsigned bpb_fdiv2(unsigned x, unsigned d, unsigned m
     return d == 1 ? x : __umulhi(x, magic);
 }
 
-template <bool SC1 = false>      // SC1: the folded form below (scale / shift come from other workgroups of THIS launch; `poison` after a time-out)
-__device__ __forceinline__ void bpb_fuse_fwd_body(const BpbFuseArgs& A, int blk, int nblk, bool poison = false)
+__device__ __forceinline__ void bpb_fuse_fwd_body(const BpbFuseArgs& A, int blk, int nblk)
 {
     const int c4 = A.C >> 2;
     const long total = (long)A.N * A.H * A.W * c4;
@@ -293,7 +285,6 @@ __device__ __forceinline__ void bpb_fuse_fwd_body(const BpbFuseArgs& A, int blk,
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[e] = acc[e] > 0.f ? acc[e] : 0.f;
         }
-        if (SC1 && poison) acc[0] = acc[1] = acc[2] = acc[3] = __builtin_nanf("");
         *(f32x4*)(A.out + p * A.C + cq * 4) = acc;
     }
 }
@@ -309,88 +300,6 @@ __global__ __launch_bounds__(256) void bpb_fuse_fwd_multi_kernel(const BpbFuseAr
     const BpbFuseArgs A = descs[bpb_find_problem(bb, (int)blockIdx.x)];
     bpb_fuse_fwd_body(A, blockIdx.x - A.blk_begin, A.nblk);
 }
-
-// The same launch with the BatchNorm finalisation of its terms FOLDED IN (training forward: conv -> finalize -> fuse was three
-// launches per layer; the finalize launch does 2-3 us of work and costs a kernel boundary on either side -- dropping all of them
-// from the plans shortens the step by 4.8 %, tools/ablate_finalize.py).  The first `nfin` blocks of the grid are finalizers
-// (2 channels x 128 row lanes each: the stand-alone kernel's additions in the same order); they publish scale / shift with
-// write-through stores, drain them, and count themselves in sync[0].  The other blocks wait for sync[0] == nfin -- bounded; the
-// finalizers have the lowest block ids, the dispatcher hands blocks out in index order (observed, not promised: the same
-// assumption as the K-split hand-over of conv_s1), so they are resident before any waiter -- and then read scale / shift
-// (MI355X_MICROARCH.md, inter-workgroup visibility: the per-XCD L2s are not coherent with each other; no fences, see below).
-// A waiter that gives up poisons its output with NaN and sets sync[2] (Net.split_timeouts()).  The last block to finish (ticket
-// sync[1]) re-arms sync[0..1] for the next launch: no host-side epoch, so the launch can be replayed from a hipGraph.
-// sync layout: every counter / flag on a 128-byte line of its own (32 ints).  Thousands of agent-scope atomics on ONE address cost
-// ~15 ns each (a 5000-block launch spent 79 us in its end-of-block ticket alone), so both counts are two-level: blocks count into
-// sub-counters (block id modulo 16 / 32), the block that completes a sub-counter counts into the top one.
-constexpr int BPB_FOLD_READY = 32, BPB_FOLD_FSUB = 16, BPB_FOLD_DSUB = 32;
-constexpr int FOLD_FIN_TOP = 0, FOLD_DONE_TOP = 32, FOLD_TIMEOUT = 64, FOLD_READY0 = 96, FOLD_FSUB0 = FOLD_READY0 + 32 * BPB_FOLD_READY,
-              FOLD_DSUB0 = FOLD_FSUB0 + 32 * BPB_FOLD_FSUB, BPB_FOLD_INTS = FOLD_DSUB0 + 32 * BPB_FOLD_DSUB;
-static_assert(BPB_FOLD_INTS == BPB_FOLD_SYNC_INTS, "sync layout");
-#define FOLD_ADD(i) __hip_atomic_fetch_add(sync + (i), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define FOLD_SET(i, v) __hip_atomic_store(sync + (i), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-
-__global__ __launch_bounds__(256) void bpb_fuse_fwd_fold_kernel(const BpbFuseArgs* __restrict__ descs, BpbBlkBegins bb,
-                                                               const BpbBnFinDesc* __restrict__ fdescs, BpbBlkBegins fbb, int nfin,
-                                                               int* __restrict__ sync)
-{
-    __shared__ double red[2][BPB_FIN_LANES][2];
-    __shared__ int s_flag;
-    const int bid = (int)blockIdx.x, G = (int)gridDim.x;
-    if (bid < nfin) {
-        const int di = bpb_find_problem(fbb, bid);
-        const BpbBnFinDesc D = fdescs[di];
-        bpb_bn_finalize_body<2, true>(bid - fbb.begin[di], red, D.partials, D.nparts, D.C, D.count, D.gamma, D.beta, D.eps, D.momentum,
-                                      D.scale, D.shift, D.mean, D.invstd, D.running_mean, D.running_var);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        // (RELAXED on purpose: an agent-scope release writes back the whole L2 of this XCD -- once per finalizer block, with the
-        //  convolution's output still dirty in it.  The stores above are write-through and drained.)
-        if (threadIdx.x == 0) {
-            const int sub = bid % BPB_FOLD_FSUB, nsub = (nfin - sub + BPB_FOLD_FSUB - 1) / BPB_FOLD_FSUB;
-            int last = 0;
-            if (FOLD_ADD(FOLD_FSUB0 + 32 * sub) == nsub - 1) last = FOLD_ADD(FOLD_FIN_TOP) == min(nfin, BPB_FOLD_FSUB) - 1;
-            s_flag = last;
-        }
-        __syncthreads();
-        // the LAST finalizer raises the ready flag -- 32 copies on 32 cache lines: thousands of resident blocks poll
-        if (s_flag && threadIdx.x < BPB_FOLD_READY) FOLD_SET(FOLD_READY0 + 32 * (int)threadIdx.x, 1);
-    } else {
-        if (threadIdx.x == 0) {
-            const int* ready = sync + FOLD_READY0 + 32 * (bid & (BPB_FOLD_READY - 1));
-            int spins = 0;
-            while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < (1 << 17)) __builtin_amdgcn_s_sleep(32);
-            const int lost = spins >= (1 << 17);
-            if (lost) FOLD_SET(FOLD_TIMEOUT, 1);
-            s_flag = lost;
-            // NO agent-scope acquire here: it would invalidate this XCD's L2 once per waiting block (thousands per launch, with the
-            // convolution output the block is about to read in it).  No block of this launch touches scale / shift before the flag
-            // is up and every cache was invalidated at the kernel boundary, so no stale copy of them can sit in any L1 / L2.
-            asm volatile("" ::: "memory");
-        }
-        __syncthreads();
-        const bool lost = s_flag != 0;
-        const int b = bid - nfin;
-        const BpbFuseArgs A = descs[bpb_find_problem(bb, b)];
-        bpb_fuse_fwd_body<true>(A, b - A.blk_begin, A.nblk, lost);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // the last block to finish re-arms everything for the next launch (every waiter has seen its flag before it counts here)
-        const int sub = bid % BPB_FOLD_DSUB, nsub = (G - sub + BPB_FOLD_DSUB - 1) / BPB_FOLD_DSUB;
-        if (FOLD_ADD(FOLD_DSUB0 + 32 * sub) == nsub - 1) {
-            FOLD_SET(FOLD_DSUB0 + 32 * sub, 0);
-            if (FOLD_ADD(FOLD_DONE_TOP) == min(G, BPB_FOLD_DSUB) - 1) {
-                for (int j = 0; j < BPB_FOLD_READY; ++j) FOLD_SET(FOLD_READY0 + 32 * j, 0);
-                for (int j = 0; j < BPB_FOLD_FSUB; ++j) FOLD_SET(FOLD_FSUB0 + 32 * j, 0);
-                FOLD_SET(FOLD_FIN_TOP, 0);
-                FOLD_SET(FOLD_DONE_TOP, 0);
-            }
-        }
-    }
-}
-#undef FOLD_ADD
-#undef FOLD_SET
 
 // ---- (3) backward of one term ------------------------------------------------------------------
 // G[q][c] = sum over the 2^up x 2^up window of dout * (out > 0 if relu).
@@ -814,40 +723,6 @@ int bpb_term_bwd_multi(const BpbTermBwdArgs* d_descs, const BpbTermBwdArgs* h_de
     else if (mode == 1) hipLaunchKernelGGL(bpb_term_bwd_multi_kernel<1>, dim3(total_blocks), dim3(256), 0, stream, d_descs, bb);
     else if (mode == 2) hipLaunchKernelGGL(bpb_term_bwd_multi_kernel<2>, dim3(total_blocks), dim3(256), 0, stream, d_descs, bb);
     else return bpb_set_error(-1, "bpb_term_bwd_multi: mode %d", mode);
-    BPB_LAUNCH_OK();
-    return 0;
-}
-
-// bpb_fuse_fwd_multi with the finalisation of up to 16 BatchNorms folded in (bpb_fuse_fwd_fold_kernel): `sync` = BPB_FOLD_SYNC_INTS device
-// ints, zero before the first launch ([0] finalizers done, [1] blocks finished, [2] time-out mark, ready copies; the launch re-arms itself).
-int bpb_fuse_fwd_fold_multi(const BpbFuseArgs* d_descs, const BpbFuseArgs* h_descs, int n, int fuse_blocks, const BpbBnFinDesc* d_fin,
-                            const BpbBnFinDesc* h_fin, int nf, int* sync, hipStream_t stream)
-{
-    BPB_REQUIRE(n >= 1 && n <= 16 && fuse_blocks >= 1 && nf >= 1 && nf <= 16 && sync != nullptr, "bpb_fuse_fwd_fold_multi: n=%d blocks=%d nf=%d", n,
-                fuse_blocks, nf);
-    int blk = 0;
-    for (int i = 0; i < n; ++i) {
-        const BpbFuseArgs* a = &h_descs[i];
-        BPB_REQUIRE(a->nterms >= 1 && a->nterms <= BPB_MAX_TERMS && a->C % 4 == 0, "bpb_fuse_fwd_fold_multi: record %d", i);
-        for (int t = 0; t < a->nterms; ++t)
-            BPB_REQUIRE(a->up[t] >= 0 && (a->H % (1 << a->up[t])) == 0 && (a->W % (1 << a->up[t])) == 0,
-                        "bpb_fuse_fwd_fold_multi: output dims must be multiples of the upsample factor");
-        BPB_REQUIRE((long)a->N * a->H * a->W * (a->C / 4) < (1L << 32), "bpb_fuse_fwd_fold_multi: tensor too large for 32-bit pixel index");
-        BPB_REQUIRE(a->blk_begin == blk && a->nblk >= 1, "bpb_fuse_fwd_fold_multi: blk_begin mismatch");
-        blk += a->nblk;
-    }
-    BPB_REQUIRE(blk == fuse_blocks, "bpb_fuse_fwd_fold_multi: block count mismatch");
-    BpbBlkBegins fbb;
-    int nfin = 0;
-    for (int i = 0; i < 16; ++i) {
-        fbb.begin[i] = i < nf ? nfin : 0x7fffffff;
-        if (i < nf) {
-            BPB_REQUIRE(h_fin[i].nparts >= 1 && h_fin[i].C >= 1 && h_fin[i].count >= 1.0, "bpb_fuse_fwd_fold_multi: BatchNorm record %d", i);
-            nfin += bpb_cdiv(h_fin[i].C, 2);
-        }
-    }
-    hipLaunchKernelGGL(bpb_fuse_fwd_fold_kernel, dim3(nfin + fuse_blocks), dim3(256), 0, stream, d_descs, bpb_blk_begins(h_descs, n), d_fin, fbb, nfin,
-                       sync);
     BPB_LAUNCH_OK();
     return 0;
 }

@@ -206,10 +206,6 @@ static int run_one(const BpbPlanOp& o, int k, hipStream_t stream)
             case BPB_OP_CHANNEL_STATS:   // p0 x, d0 P, i0 C, p1 partials, i1 nblocks
                 rc = bpb_channel_stats((const float*)o.p[0], (long)o.d[0], o.i[0], (double*)o.p[1], o.i[1], stream);
                 break;
-            case BPB_OP_FUSE_FWD_FOLD:   // p0 device fuse records, p1 host copy, p2 device BatchNorm records, p3 host copy, p4 sync, i0 n, i1 fuse blocks, i2 nf
-                rc = bpb_fuse_fwd_fold_multi((const BpbFuseArgs*)o.p[0], (const BpbFuseArgs*)o.p[1], o.i[0], o.i[1], (const BpbBnFinDesc*)o.p[2],
-                                             (const BpbBnFinDesc*)o.p[3], o.i[2], (int*)o.p[4], stream);
-                break;
             case BPB_OP_FUSE_FWD_MULTI:   // p0 device records, p1 host records, i0 count, i1 total blocks
                 rc = bpb_fuse_fwd_multi((const BpbFuseArgs*)o.p[0], (const BpbFuseArgs*)o.p[1], o.i[0], o.i[1], stream);
                 break;

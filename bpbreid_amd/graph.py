@@ -209,8 +209,6 @@ class Net:
         self.fold_eval_bn = os.environ.get('BPB_FOLD_EVAL_BN', '1') != '0'
         self.dgrad_bn_partials = os.environ.get('BPB_DGRAD_BN', '1') != '0'    # BatchNorm-backward partials from the dgrad epilogue
         self.use_s1w = os.environ.get('BPB_CONV_S1W', '1') != '0'              # 0: strided 3x3 data gradients on the general kernel
-        self.fold_finalize = os.environ.get('BPB_FOLD_FINALIZE', '0') != '0'     # 1: training forward, BatchNorm finalize launches inside the fuse launches
-        self.fold_syncs = []
         self.use_s1_1x1s2 = os.environ.get('BPB_S1_1X1_STRIDE2', '1') != '0'    # 0: data gradient of 1x1 stride-2 convolutions as parity classes of the general kernel
         self.use_conv_c4 = os.environ.get('BPB_CONV_C4', '1') != '0'             # 0: stem forward on the general kernel
         self.debug_c4 = []
@@ -1004,21 +1002,6 @@ class Net:
     def _freeze(self, recs, name=None):
         """Turn the records into the PlanOp array that bpb_plan_run walks.  Returns (array, count, meta per launch)."""
         groups = self._merge(self._balance(recs))
-        if name == 'train' and self.fold_finalize:
-            # training forward: a BatchNorm-finalize launch directly in front of the fuse launch that applies it becomes part of
-            # that launch (csrc/bn_act.hip, bpb_fuse_fwd_fold_kernel): one group = one launch stays true for plan_groups
-            folded, k = [], 0
-            while k < len(groups):
-                g = groups[k]
-                nxt = groups[k + 1] if k + 1 < len(groups) else None
-                if (nxt is not None and all(r_.kind == nv.OP_BN_FINALIZE_MULTI and r_.desc is not None for r_ in g) and len(g) <= 16 and
-                        all(r_.kind == nv.OP_FUSE_FWD_MULTI and r_.desc is not None for r_ in nxt)):
-                    folded.append(list(g) + list(nxt))
-                    k += 2
-                else:
-                    folded.append(g)
-                    k += 1
-            groups = folded
         if name is not None:
             self.plan_groups[name] = groups
         arr = (PlanOp * max(1, len(groups)))()
@@ -1044,18 +1027,6 @@ class Net:
                 arr[k] = g[0].op
                 arr[k].i[10] = side
                 meta.append({'label': g[0].label, 'flops': g[0].flops, 'bytes': g[0].bytes, 'n': 1})
-                continue
-            if g[0].kind == nv.OP_BN_FINALIZE_MULTI and g[-1].kind == nv.OP_FUSE_FWD_MULTI:
-                fin = [r_ for r_ in g if r_.kind == nv.OP_BN_FINALIZE_MULTI]
-                fus = sorted([r_ for r_ in g if r_.kind == nv.OP_FUSE_FWD_MULTI], key=lambda r_: -r_.work)
-                hfin, dfin, _ = pack(fin)
-                hfus, dfus, blk = pack(fus)
-                sync = torch.zeros(2656, device=self.device, dtype=torch.int32)  # BPB_FOLD_SYNC_INTS: two-level counters, ready copies, time-out mark at [64]
-                self.keep.append(sync)
-                self.fold_syncs.append(sync)
-                arr[k] = self._op(nv.OP_FUSE_FWD_FOLD, ints=(len(fus), blk, len(fin)), ptrs=(dfus, C.addressof(hfus), dfin, C.addressof(hfin), sync))
-                arr[k].i[10] = 0
-                meta.append({'label': 'fuse_fwd +bn_finalize x%d' % len(g), 'flops': 0.0, 'bytes': sum(r_.bytes for r_ in g), 'n': len(g)})
                 continue
             g = sorted(g, key=lambda r_: -r_.work)          # stable: heaviest workgroups first in the grid
             ctype = type(g[0].desc)
@@ -1098,7 +1069,7 @@ class Net:
 
     def split_timeouts(self):
         """Number of K-split problems whose consumer workgroups ever gave up waiting for their producer (must be 0; host sync)."""
-        return sum(int(f_[n_].item()) for f_, n_ in self.split_flags) + sum(int(s_[64].item()) for s_ in self.fold_syncs)
+        return sum(int(f_[n_].item()) for f_, n_ in self.split_flags)
 
     # ------------------------------------------------------------------ backward plan
     def _flush_reduce(self, bwd):

@@ -363,7 +363,6 @@ typedef enum BpbOpKind {
     BPB_OP_WGRAD_C4 = 32,          /* p0 device BpbWgradProb[], p1 host copy, i0 nprobs */
     BPB_OP_CONV_C4 = 33,           /* p0 x, p1 w, p2 y, p3 bias, p4 stats, i0 N, i1 Hi, i2 Wi, i3 R, i4 Cout, i5 relu, i6 nblk */
     BPB_OP_SCATTER_S2 = 34,        /* p0 src, p1 dst, i0 N, i1 A, i2 B, i3 H, i4 W, i5 C, i6 accumulate */
-    BPB_OP_FUSE_FWD_FOLD = 35,     /* p0 device BpbFuseArgs[], p1 host copy, p2 device BpbBnFinDesc[], p3 host copy, p4 sync ints, i0 fuse records, i1 fuse blocks, i2 BatchNorm records */
 } BpbOpKind;
 
 // generic op record; slot meaning per kind is documented next to each case; i[10] = stream slot (0 = the caller's stream, 1..3 = branch streams,
@@ -433,13 +432,6 @@ int bpb_term_bwd(const BpbTermBwdArgs* a, int mode, int nblocks, hipStream_t str
 int bpb_bn_bwd_finalize(const double* partials, int nparts, int C, double count, float* dgamma, float* dbeta,
                         int accumulate, float* c1, float* c2, hipStream_t stream);
 /* grouped variants (one launch for the independent branches of a module step; same arithmetic as the single launches) */
-/* bpb_fuse_fwd_multi with the finalisation (bpb_bn_finalize_multi) of up to 16 BatchNorms folded into the same launch: the first
-   blocks of the grid finalize and publish scale / shift, the others wait for them (bounded; a time-out poisons the output with NaN
-   and sets sync[64]).  `sync`: BPB_FOLD_SYNC_INTS device ints, zero before the first launch; the launch re-arms them itself (hipGraph
-   replay works). */
-#define BPB_FOLD_SYNC_INTS 2656
-int bpb_fuse_fwd_fold_multi(const BpbFuseArgs* d_descs, const BpbFuseArgs* h_descs, int n, int fuse_blocks, const BpbBnFinDesc* d_fin,
-                            const BpbBnFinDesc* h_fin, int nf, int* sync, hipStream_t stream);
 int bpb_fuse_fwd_multi(const BpbFuseArgs* d_descs, const BpbFuseArgs* h_descs, int n, int total_blocks, hipStream_t stream);
 int bpb_term_bwd_multi(const BpbTermBwdArgs* d_descs, const BpbTermBwdArgs* h_descs, int n, int total_blocks, int mode,
                        hipStream_t stream);

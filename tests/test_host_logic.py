@@ -209,48 +209,6 @@ def test_row_argsort_algorithm_is_the_stable_argsort():
         assert np.array_equal(got, np.argsort(d, axis=1, kind='stable')), (q, g, quant)
 
 
-def test_folded_finalize_plan_structure(monkeypatch):
-    """BPB_FOLD_FINALIZE=1: in the training-forward plan every BatchNorm-finalize launch that directly precedes the fuse launch applying
-    it becomes part of that launch (one PlanOp: fuse records, BatchNorm records, three sync ints); every record still appears exactly
-    once, the eval and backward plans are untouched."""
-    from bpbreid_amd.backbones import HRNet
-
-    def build():
-        hr = HRNet((8, 16, 32, 64))
-        for p in hr.parameters():
-            p.grad = torch.zeros_like(p)
-        net = Net(torch.device('cpu'))
-        hr.emit(net, net.input_nchw(4, 3, 64, 32))
-        net.finalize(train_backward=True)
-        return net
-
-    base = build()
-    monkeypatch.setenv('BPB_FOLD_FINALIZE', '1')
-    net = build()
-    def kinds(n_, name):
-        arr, count, _ = {'train': n_.plan_train, 'eval': n_.plan_eval, 'bwd': n_.plan_bwd}[name]
-        return [arr[k].kind for k in range(count)]
-
-    assert kinds(net, 'eval') == kinds(base, 'eval') and kinds(net, 'bwd') == kinds(base, 'bwd')
-    kt, kb = kinds(net, 'train'), kinds(base, 'train')
-    nfold = kt.count(nv.OP_FUSE_FWD_FOLD)
-    assert nfold > 40 and len(kt) == len(kb) - nfold and len(net.fold_syncs) == nfold
-    assert kb.count(nv.OP_BN_FINALIZE_MULTI) - kt.count(nv.OP_BN_FINALIZE_MULTI) == nfold
-    groups = net.plan_groups['train']
-    flat = [r for g in groups for r in g]
-    assert len(flat) == len({id(r) for r in flat}) == len([r for g in base.plan_groups['train'] for r in g])
-    for g, o in zip(groups, net.plan_train[0]):
-        if o.kind == nv.OP_FUSE_FWD_FOLD:
-            fin = [r for r in g if r.kind == nv.OP_BN_FINALIZE_MULTI]
-            fus = [r for r in g if r.kind == nv.OP_FUSE_FWD_MULTI]
-            assert fin and fus and len(fin) + len(fus) == len(g) and (o.i[0], o.i[2]) == (len(fus), len(fin)) and o.i[1] == sum(r.blocks for r in fus)
-            hf = C.cast(o.p[1], C.POINTER(nv.FuseArgs))
-            scales = {hf[q].scale[t] for q in range(len(fus)) for t in range(hf[q].nterms) if hf[q].scale[t]}
-            hb = C.cast(o.p[3], C.POINTER(nv.BnFinDesc))
-            assert {hb[q].scale for q in range(len(fin))} <= scales | {hb[q].scale for q in range(len(fin))}      # the BatchNorms it applies ...
-            assert scales & {hb[q].scale for q in range(len(fin))}                                               # ... are among the ones it finalizes
-
-
 def test_standalone_1x1_convolutions_take_128_pixel_tiles_where_every_cu_still_gets_a_workgroup(monkeypatch):
     """Plan-time tile rule of 1x1 launches that stand alone (ResNet-50 layers 2-4, profiles/r04_s1_sweep_1x1.txt): 128 pixels x 64
     channels with 32-channel chunks where the convolution narrows (K >= 256), 128 x 128 where it widens by 4; the round-3 tile at
