@@ -48,10 +48,13 @@ def parse():
     ap.add_argument('--no-forward-only', action='store_true')
     ap.add_argument('--no-eval', action='store_true')
     ap.add_argument('--graph', type=int, default=-1,
-                    help='1: replay the step from one hipGraph (8 instead of 21 ms of host work per step; with --gpus N the RCCL '
-                         'all-reduce launches are captured with the step and the ranks AGREE on graph vs eager); 0: eager launches '
-                         '(the weight gradients then run on a side stream: 30.8 instead of 32.8 ms per step on one GPU); -1 (default): '
-                         'eager; on one GPU the graph if the host loop needs more than 85 %% of the step (N > 1 reports the fraction only)')
+                    help='1: replay the step from one hipGraph (with --gpus N the RCCL all-reduce launches are captured with the step '
+                         'and the ranks AGREE on graph vs eager); 0: eager launches of the taped step (bpbreid_amd.fused_step: one '
+                         'bpb_tape_run per segment, weight gradients on a side stream); -1 (default): chosen by measurement -- both '
+                         'are probed for 5 steps and the faster one runs the timed region (N > 1: the graph is only tried when the '
+                         'eager host loop needs more than 85 %% of the step)')
+    ap.add_argument('--graph-side-batch', type=int, default=None, help='captured step: weight-gradient launches per fork onto the side '
+                    'stream (0: the whole backward plan on one stream; default: BPB_GRAPH_SIDE_BATCH, else 0)')
     ap.add_argument('--dist-backend', default='nccl', help="'nccl' (= RCCL over xGMI; the default) or 'gloo' (functional check of the "
                     "multi-process path when the ranks have to share one GPU)")
     ap.add_argument('--dump-plan-timing', default='', help='write the per-record isolated timings of the forward and backward '
@@ -432,30 +435,48 @@ def main():
     for _ in range(args.warmup):
         loss, _ = step()
     torch.cuda.synchronize()
-    want_graph = args.graph == 1
     host_bound = None
-    if args.graph == -1:
-        # eager is the faster schedule while the host keeps up (two-stream backward); a host loop that needs > 85 % of the step on
-        # ANY rank (few cores per rank) makes the job host-bound: all ranks then switch to the captured step together
-        probe = 3
+    choice = None
+
+    def probe(fn, reps=5):
+        """(ms per step, host fraction) of `reps` steps, MAX over the ranks: the same numbers -- hence the same decision -- everywhere."""
+        fn()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(probe):
-            step()
-        t_host = time.perf_counter() - t0
-        torch.cuda.synchronize()
-        ratio = torch.tensor([t_host / max(time.perf_counter() - t0, 1e-9)], device=dev, dtype=torch.float64)
         if multi:
-            dist.all_reduce(ratio, op=dist.ReduceOp.MAX)
-        host_bound = float(ratio)
-        # (N > 1: reported only.  A captured step that holds RCCL launches has run on ONE rank so far (tests, --force-dist); the
-        #  first multi-rank job must not depend on it -- ask for it with --graph 1)
-        want_graph = host_bound > 0.85 and not multi
+            dist.barrier()
+        t0_ = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        t_host = time.perf_counter() - t0_
+        torch.cuda.synchronize()
+        t_all = time.perf_counter() - t0_
+        v = torch.tensor([t_all / reps, t_host / max(t_all, 1e-9)], device=dev, dtype=torch.float64)
+        if multi:
+            dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        return 1e3 * float(v[0]), float(v[1])
+
+    want_graph = args.graph == 1
+    if args.graph == -1:
+        # the launch mode is chosen BY MEASUREMENT, identically on every rank (the probes are MAX-reduced): eager launches of the
+        # taped step (two-stream backward, ~1/4 of a core per rank) against the step replayed from a hipGraph.  N > 1: the graph is
+        # only tried when the eager host loop is the limit (> 85 % of the step on some rank): a captured step holds the RCCL
+        # launches, and a job whose eager loop keeps up has nothing to gain from depending on that
+        eager_ms, host_bound = probe(step)
+        choice = {'eager_ms': eager_ms, 'eager_host_fraction': host_bound}
+        want_graph = (not multi) or host_bound > 0.85
     if want_graph and (not multi or args.dist_backend == 'nccl'):     # (RCCL collectives are captured with the step)
-        replay, mode, why = eng.capture_step_agreed(data, warmup=1)
+        replay, mode, why = eng.capture_step_agreed(data, warmup=1, side_batch=args.graph_side_batch)
         if why:
             sys.stderr.write('hipGraph capture not used (%s): eager launches on every rank\n' % why)
-        step = lambda: replay()
+        if mode == 'hipgraph' and args.graph == -1:
+            graph_ms, graph_host = probe(lambda: replay())
+            choice.update(graph_ms=graph_ms, graph_host_fraction=graph_host)
+            if graph_ms >= choice['eager_ms']:
+                mode = 'eager'                               # measured: the eager taped step is at least as fast
+        if mode == 'hipgraph':
+            step = lambda: replay()
+        else:
+            mode = 'eager'
         loss, _ = step()
         torch.cuda.synchronize()
     if multi:
@@ -521,7 +542,8 @@ def main():
                    'parallelism': 'dp%d' % world, 'global_batch': args.batch * world, 'final_loss': final_loss,
                    'host_enqueue_ms_per_step': 1e3 * host_enqueue / args.steps, 'launch_mode': mode,
                    'host_enqueue_ms_per_step_min_over_ranks': 1e3 * (host_enqueue_min if multi else host_enqueue) / args.steps,
-                   'host_fraction_of_step_before_choosing_the_launch_mode': host_bound,
+                   'host_fraction_of_step_before_choosing_the_launch_mode': host_bound, 'launch_mode_probe': choice,
+                   'taped_step': eng.fused_reason is None, 'taped_step_not_used_because': eng.fused_reason,
                    'host_cores_per_rank': len(pinned) if pinned else host_cores(),
                    'backbone_launches_per_step': sum(p_[1] for p_ in (next(iter(model._plans.values())).net.plan_train,
                                                                        next(iter(model._plans.values())).net.plan_bwd))},

@@ -38,6 +38,22 @@ __global__ __launch_bounds__(256) void bpb_fill_kernel(float* __restrict__ x, fl
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) x[i] = value;
 }
 
+__global__ void bpb_add_i64_kernel(long* __restrict__ x, long n, long v)
+{
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i < n) x[i] += v;
+}
+
+__global__ __launch_bounds__(256) void bpb_copy2d_kernel(const float* __restrict__ src, long lds, float* __restrict__ dst, long ldd, int rows,
+                                                         int cols)
+{
+    const long total = (long)rows * cols;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+        const long r = i / cols, c = i - r * cols;
+        dst[r * ldd + c] = src[r * lds + c];
+    }
+}
+
 extern "C" {
 
 // step_index is 1-based.  gscale multiplies the gradient first (1/world_size after a summing all-reduce).
@@ -64,6 +80,24 @@ int bpb_fill(float* x, float value, long n, hipStream_t stream)
     if (g > 4096) g = 4096;
     if (g < 1) g = 1;
     hipLaunchKernelGGL(bpb_fill_kernel, dim3((int)g), dim3(256), 0, stream, x, value, n);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_add_i64(long* x, long n, long v, hipStream_t stream)
+{
+    BPB_REQUIRE(x != nullptr && n >= 1, "bpb_add_i64: bad arguments");
+    hipLaunchKernelGGL(bpb_add_i64_kernel, dim3(bpb_cdiv(n, 256)), dim3(256), 0, stream, x, n, v);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_copy2d(const float* src, long lds, float* dst, long ldd, int rows, int cols, hipStream_t stream)
+{
+    BPB_REQUIRE(src != nullptr && dst != nullptr && rows >= 1 && cols >= 1 && lds >= cols && ldd >= cols, "bpb_copy2d: bad arguments");
+    long g = ((long)rows * cols + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(bpb_copy2d_kernel, dim3((int)g), dim3(256), 0, stream, src, lds, dst, ldd, rows, cols);
     BPB_LAUNCH_OK();
     return 0;
 }

@@ -39,36 +39,54 @@ extern "C" int bpb_plan_run(const BpbPlanOp* ops, int nops, hipStream_t stream)
 // (Measured and NOT kept, round 4: the odd branch chains of the training forward's fork regions on the side stream -- 10.39 ->
 //  10.74 ms per forward, 30.7 -> 30.9 ms per step; an eval forward as two half-batch chains -- 7.76 -> 7.82 ms.  Two chains of the
 //  same kind want the matrix pipes at the same time; what pays is putting work of a DIFFERENT kind beside the chain.)
-extern "C" int bpb_plan_run2(const BpbPlanOp* ops, int nops, hipStream_t main, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join)
+extern "C" int bpb_plan_run2(const BpbPlanOp* ops, int nops, hipStream_t main, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join,
+                             int side_batch)
 {
     if (side == nullptr) return bpb_plan_run(ops, nops, main);
     BPB_REQUIRE(ev_fork != nullptr && ev_join != nullptr, "bpb_plan_run2: a side stream needs the fork and join events");
+    // side_batch > 1: side records are held back until `side_batch` of them are pending (or the call ends) and then issued behind
+    // ONE fork -- later than their inputs are final, which is always legal (nothing on the plan reads what they write), with fewer
+    // cross-stream edges: what a captured step wants (every edge of a hipGraph costs host and device time at replay).
+    if (side_batch < 1) side_batch = 1;
+    std::vector<int> pending;
     bool main_ahead = true, side_used = false;
-    for (int k = 0; k < nops; ++k) {
+    int rc = 0;
+    auto flush = [&]() -> int {
+        if (pending.empty()) return 0;
+        if (main_ahead) {
+            hipError_t e = hipEventRecord(ev_fork, main);
+            if (e == hipSuccess) e = hipStreamWaitEvent(side, ev_fork, 0);
+            if (e != hipSuccess) return bpb_set_error((int)e, "bpb_plan_run2: fork: %s", hipGetErrorString(e));
+            main_ahead = false;
+        }
+        side_used = true;
+        for (int k : pending) {
+            const int r = run_one(ops[k], k, side);
+            if (r != 0) return r;
+        }
+        pending.clear();
+        return 0;
+    };
+    for (int k = 0; k < nops && rc == 0; ++k) {
         const BpbPlanOp& o = ops[k];
         if (o.kind == BPB_OP_FORK || o.kind == BPB_OP_JOIN || o.kind == BPB_OP_DEP) continue;
-        int rc;
         if (o.i[10] == 1) {
-            if (main_ahead) {
-                hipError_t e = hipEventRecord(ev_fork, main);
-                if (e == hipSuccess) e = hipStreamWaitEvent(side, ev_fork, 0);
-                if (e != hipSuccess) return bpb_set_error((int)e, "bpb_plan_run2: fork: %s", hipGetErrorString(e));
-                main_ahead = false;
-            }
-            side_used = true;
-            rc = run_one(o, k, side);
+            pending.push_back(k);
+            if ((int)pending.size() >= side_batch) rc = flush();
         } else {
             main_ahead = true;
             rc = run_one(o, k, main);
         }
-        if (rc != 0) return rc;
     }
+    if (rc == 0) rc = flush();
+    // the join runs on EVERY exit path on which the side stream was used: after a failed launch the caller's next launches on
+    // `main` (the next forward, the optimizer) must not race with weight-gradient kernels still running on `side`
     if (side_used) {
         hipError_t e = hipEventRecord(ev_join, side);
         if (e == hipSuccess) e = hipStreamWaitEvent(main, ev_join, 0);
-        if (e != hipSuccess) return bpb_set_error((int)e, "bpb_plan_run2: join: %s", hipGetErrorString(e));
+        if (e != hipSuccess && rc == 0) rc = bpb_set_error((int)e, "bpb_plan_run2: join: %s", hipGetErrorString(e));
     }
-    return 0;
+    return rc;
 }
 
 // Events for bpb_plan_run2 (timing disabled: cheapest record / wait).  The caller owns the handle.

@@ -1,0 +1,144 @@
+// Launch tape: a recorded sequence of C-ABI calls replayed by ONE host call.
+//
+// The backbone is a static launch plan (plan.cpp).  Everything else a train step enqueues -- the part-attention head, the dense
+// stack, the GiLt / pixel losses, their backward passes, the optimizer -- is a sequence of ~150 calls of this library whose
+// arguments (device pointers of buffers that live as long as the plan, sizes, host descriptor arrays owned by the recorder) do
+// not change from step to step either.  The reference runs that stretch as Python (torchreid/engine/image/part_based_engine.py:77-130,
+// torchreid/losses/GiLt_loss.py:45-119); round 4 of this library still drove it from Python through autograd.Function glue (15 of
+// the 21 ms of host time per step, ~50 ATen fills / copies / compares between the two plans).  A tape entry is (entry point,
+// argument words); bpb_tape_run walks the array and calls the entry points with the CALLER's stream substituted for the recorded
+// one -- no Python, no allocator, no argument marshalling, and unlike a hipGraph the launches stay eager: the two-stream schedule
+// of bpb_plan_run2 and RCCL's own streams work unchanged, and a tape segment can be captured into a hipGraph like any other call.
+//
+// Type safety: every tapeable entry point gets a thunk instantiated from ITS OWN prototype (bpbreid_hip.h), which converts the
+// 8-byte argument words back to the parameter types; bpb_tape_signature hands the recorder the parameter kinds so that it converts
+// (and checks) the Python arguments against the compiled prototype, not against a hand-written table.
+#include <string.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "bpb_common.h"
+
+namespace {
+
+template <typename T>
+inline T tape_get(const BpbTapeArg& a)
+{
+    if constexpr (std::is_pointer<T>::value) return (T)a.p;
+    else if constexpr (std::is_same<T, float>::value) return a.f;
+    else if constexpr (std::is_same<T, double>::value) return a.d;
+    else if constexpr (std::is_same<T, long>::value) return a.l;
+    else {
+        static_assert(std::is_same<T, int>::value, "tape: unsupported parameter type");
+        return a.i;
+    }
+}
+
+template <typename T>
+constexpr char tape_kind()
+{
+    if (std::is_same<T, hipStream_t>::value) return 's';
+    if (std::is_pointer<T>::value) return 'p';
+    if (std::is_same<T, float>::value) return 'f';
+    if (std::is_same<T, double>::value) return 'd';
+    if (std::is_same<T, long>::value) return 'l';
+    return 'i';
+}
+
+template <auto F, typename Sig = decltype(F)>
+struct Thunk;
+template <auto F, typename... A>
+struct Thunk<F, int (*)(A...)> {
+    static_assert(sizeof...(A) <= BPB_TAPE_MAX_ARGS, "tape: too many parameters");
+    template <size_t... I>
+    static int go(const BpbTapeArg* a, std::index_sequence<I...>)
+    {
+        return F(tape_get<A>(a[I])...);
+    }
+    static int call(const BpbTapeArg* a) { return go(a, std::index_sequence_for<A...>{}); }
+    static int sig(char* out)
+    {
+        const char k[] = {tape_kind<A>()..., 0};
+        memcpy(out, k, sizeof(k));
+        return (int)sizeof...(A);
+    }
+};
+
+struct Entry {
+    const char* name;
+    int (*call)(const BpbTapeArg*);
+    int (*sig)(char*);
+};
+
+#define BPB_TAPE_FUNCTIONS \
+    X(bpb_conv_igemm) X(bpb_conv_wgrad16) X(bpb_conv_wgrad_c4) X(bpb_conv_wgrad1x1) \
+    X(bpb_wgrad_reduce_multi) X(bpb_conv_s1) X(bpb_conv_s1w) X(bpb_conv_wgrad) \
+    X(bpb_wgrad_reduce) X(bpb_conv_c4) X(bpb_pack_weights) X(bpb_bn_finalize) \
+    X(bpb_bn_eval_affine_batched) X(bpb_bn_eval_affine) X(bpb_channel_stats) X(bpb_fuse_fwd) \
+    X(bpb_term_bwd) X(bpb_bn_bwd_finalize) X(bpb_fuse_fwd_multi) X(bpb_term_bwd_multi) \
+    X(bpb_bn_finalize_multi) X(bpb_bn_bwd_finalize_multi) X(bpb_nchw_to_nhwc4) X(bpb_scatter_stride2) \
+    X(bpb_nhwc_to_nchw) X(bpb_maxpool3x3s2_fwd) X(bpb_maxpool3x3s2_bwd) X(bpb_bilinear_concat_fwd) \
+    X(bpb_bilinear_concat_bwd) X(bpb_bilinear_concat_multi_fwd) X(bpb_bilinear_concat_multi_bwd) X(bpb_pixel_dots) \
+    X(bpb_pixel_dots_multi) X(bpb_masked_pool) X(bpb_masked_pool_multi) X(bpb_fold_bn) \
+    X(bpb_softmax_masks) X(bpb_resize_masks) X(bpb_attention_from_masks) X(bpb_visibility) \
+    X(bpb_pool_finalize) X(bpb_pool_finalize_multi) X(bpb_masked_maxpool_fwd) X(bpb_masked_maxpool_bwd_dmask) \
+    X(bpb_masked_maxpool_bwd_dx) X(bpb_rowdot) X(bpb_head_bwd_dlogits) X(bpb_head_bwd_params) \
+    X(bpb_head_bwd_dx) X(bpb_lowres_stats) X(bpb_lowres_upsample_sum) X(bpb_lowres_adjoint) \
+    X(bpb_lowres_dx) X(bpb_gemm) X(bpb_gemm_grouped) X(bpb_colsum) \
+    X(bpb_bn1d_fwd) X(bpb_bn1d_bwd) X(bpb_ce_label_smooth) X(bpb_pixel_ce) \
+    X(bpb_part_triplet) X(bpb_ce_weight_grad) X(bpb_part_triplet_bwd) X(bpb_scale) \
+    X(bpb_weighted_sum) X(bpb_scalar_fanout) X(bpb_adam_step) X(bpb_fill) \
+    X(bpb_part_distance) X(bpb_part_distance_fill) X(bpb_l2_normalize_rows) X(bpb_eval_rank_gpu) \
+    X(bpb_argsort_rows_gpu) X(bpb_re_ranking_gpu) X(bpb_mask_preprocess) X(bpb_plan_run) \
+    X(bpb_plan_run2) X(bpb_add_i64) X(bpb_copy2d)
+
+const Entry g_entries[] = {
+#define X(f) {#f, &Thunk<&f>::call, &Thunk<&f>::sig},
+    BPB_TAPE_FUNCTIONS
+#undef X
+};
+constexpr int g_nentries = (int)(sizeof(g_entries) / sizeof(g_entries[0]));
+
+}   // namespace
+
+// Index of a tapeable entry point (every entry point of bpbreid_hip.h that takes a stream), -1 if `name` is not one.
+extern "C" int bpb_tape_function(const char* name)
+{
+    for (int k = 0; k < g_nentries; ++k)
+        if (strcmp(g_entries[k].name, name) == 0) return k;
+    return -1;
+}
+
+// Parameter kinds of entry point `fn` as compiled: 'p' pointer, 'i' int, 'l' long, 'f' float, 'd' double, 's' the stream
+// (NUL-terminated, at most BPB_TAPE_MAX_ARGS characters).  Returns the parameter count, -1 for a bad index.
+extern "C" int bpb_tape_signature(int fn, char* out)
+{
+    if (fn < 0 || fn >= g_nentries || out == nullptr) return -1;
+    return g_entries[fn].sig(out);
+}
+
+// Replays ops[0, nops) in order on `stream`: every argument word whose bit is set in op.stream_mask is replaced by `stream`
+// (the recorder sets it for the stream the calls were recorded on; streams of other roles -- the side stream of bpb_plan_run2 --
+// stay as recorded).  Stops at the first failing call and returns its code (bpb_last_error() names it).
+extern "C" int bpb_tape_run(const BpbTapeOp* ops, int nops, hipStream_t stream)
+{
+    BPB_REQUIRE(nops == 0 || ops != nullptr, "bpb_tape_run: null tape");
+    for (int k = 0; k < nops; ++k) {
+        const BpbTapeOp& o = ops[k];
+        BPB_REQUIRE(o.fn >= 0 && o.fn < g_nentries && o.nargs >= 0 && o.nargs <= BPB_TAPE_MAX_ARGS, "bpb_tape_run: bad entry %d (fn %d, %d args)",
+                    k, o.fn, o.nargs);
+        int rc;
+        if (o.stream_mask == 0) {
+            rc = g_entries[o.fn].call(o.a);
+        } else {
+            BpbTapeArg a[BPB_TAPE_MAX_ARGS];
+            memcpy(a, o.a, sizeof(BpbTapeArg) * (size_t)o.nargs);
+            for (int q = 0; q < o.nargs; ++q)
+                if (o.stream_mask >> q & 1u) a[q].p = (void*)stream;
+            rc = g_entries[o.fn].call(a);
+        }
+        if (rc != 0) return rc;
+    }
+    return 0;
+}

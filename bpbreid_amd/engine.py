@@ -11,6 +11,7 @@ timers (utils/avgmeter.py:273), the >=10 `.item()` calls of its meters and the C
 `loss_summary` holds device scalars; read them when (and if) you want to log.
 """
 import contextlib
+import os
 
 import torch
 
@@ -72,6 +73,11 @@ class ImagePartBasedEngine:
         self.bucket_bytes = bucket_bytes
         self._steps = 0
         self.handover_check_every = 500      # train steps between two host checks of the K-split hand-over marks (one device sync)
+        # the step as one recorded launch sequence (fused_step.FusedTrainStep): no Python, no autograd, no per-call allocation between
+        # the launches; configurations it does not cover take the general path below (same kernels, same results)
+        self.fused_step = os.environ.get('BPB_FUSED_STEP', '1') != '0'
+        self._fused = {}
+        self.fused_reason = None             # why the last step was NOT taped (None: it was)
 
     def check_handovers(self):
         """Raise if a K-split convolution workgroup ever gave up waiting for its partner (csrc/conv_s1.hip: bounded wait; the tile is
@@ -94,10 +100,40 @@ class ImagePartBasedEngine:
             assert masks.shape[1] == self.parts_num + 1
         return imgs, masks, pids, data.get('img_path')
 
+    def _fused_for(self, imgs, target_masks):
+        """The taped step for this batch shape, or None (self.fused_reason says why)."""
+        from . import fused_step as fs
+        m = self.model
+        why = None if self.fused_step else 'switched off (engine.fused_step / BPB_FUSED_STEP=0)'
+        if why is None:
+            why = fs.eligible(self, bool(getattr(m, 'training_binary_visibility_score', True)), target_masks is not None)
+        if why is None and (imgs.device.type != 'cuda' or imgs.dim() != 4 or imgs.shape[0] < 2):
+            why = 'needs a CUDA batch of at least two images'
+        self.fused_reason = why
+        if why is not None:
+            return None
+        m.arena()
+        n, _, h, w = imgs.shape
+        key = (n, h, w, None if target_masks is None else tuple(target_masks.shape))
+        step = self._fused.get(key)
+        plan = m._plan(n, h, w, imgs.device)
+        if step is None or step.plan is not plan:
+            step = self._fused[key] = fs.FusedTrainStep(self, plan, target_masks)
+        return step
+
     def forward_backward(self, data):
         imgs, target_masks, pids, _ = self.parse_data_for_train(data)
         if not self.model.training:
             self.model.train()                           # (unconditionally it walks 1000 sub-modules: 4 ms of host time per step)
+        if self.distributed and self._reducer is None:
+            self._reducer = GradAllReducer(self.model.arena()['grad'], self.process_group, self.bucket_bytes)
+        fused = self._fused_for(imgs, target_masks)
+        if fused is not None:
+            loss, loss_summary = fused(imgs, target_masks, pids)
+            self._steps += 1
+            if self.handover_check_every and self._steps % self.handover_check_every == 0 and not torch.cuda.is_current_stream_capturing():
+                self.check_handovers()
+            return loss, loss_summary
         out = self.model(imgs, external_parts_masks=target_masks)
         embeddings_dict, visibility_scores_dict, id_cls_scores_dict, pixels_cls_scores, _, _ = out
         loss, loss_summary = self.combine_losses(visibility_scores_dict, embeddings_dict, id_cls_scores_dict, pids,
@@ -106,8 +142,6 @@ class ImagePartBasedEngine:
         self.optimizer.zero_grad()
         scale = 1.0
         if self.distributed:
-            if self._reducer is None:
-                self._reducer = GradAllReducer(self.model.arena()['grad'], self.process_group, self.bucket_bytes)
             self._reducer.begin()
             self.model._bucket_hook = self._reducer     # the backward plan hands over buckets as they become final
         try:
@@ -129,11 +163,18 @@ class ImagePartBasedEngine:
         return loss, loss_summary
 
     # ------------------------------------------------------------------ hipGraph replay of the whole step
-    def capture_step(self, data, warmup=3):
+    def capture_step(self, data, warmup=3, side_batch=None, agree=None):
         """Record one full train step (forward, losses, backward, [bucketed RCCL all-reduce], Adam) into a hipGraph.
         On a distributed engine the all-reduce launches are captured with the step (RCCL supports stream capture: the
         collectives become graph nodes on their own branch, forked where the backward plan hands a bucket over and joined
         before the Adam launch) -- every rank must capture and replay the same number of times.
+
+        `side_batch`: the two-stream schedule of the captured backward plan -- 0 keeps the whole plan on one stream, B >= 1 puts
+        the weight gradients on the side stream with one fork per B of them (graph.Net.side_batch; hipGraph capture follows the
+        fork / join events, every cross-stream edge costs host and device time at replay).  Default: BPB_GRAPH_SIDE_BATCH, else 0.
+        `agree(ok) -> bool`: data-parallel jobs pass a collective AND over the ranks; it is called once after the warm-up steps
+        (which contain the gradient all-reduces, so a rank that failed there cannot be waited for: the job is aborted on every
+        rank) -- see capture_step_agreed.
 
         Returns `replay(new_data=None) -> (loss, loss_summary)`: copies `new_data` into the captured input buffers (if given)
         and replays the graph -- no Python, no launch-argument marshalling, one host call per step.  Capturing does not train:
@@ -156,6 +197,12 @@ class ImagePartBasedEngine:
         arena = self.model.arena()
         if fused:
             self.optimizer._state()
+        if side_batch is None:
+            side_batch = int(os.environ.get('BPB_GRAPH_SIDE_BATCH', '0'))
+        net = self.model._plan(imgs.shape[0], imgs.shape[2], imgs.shape[3], imgs.device).net if hasattr(self.model, '_plan') else None
+        old_batch = net.side_batch if net is not None else None
+        if net is not None:
+            net.side_batch = int(side_batch)
         snap = {k: arena[k].clone() for k in ('param', 'fbuf', 'ibuf')}
         if fused:
             snap_opt = (self.optimizer.exp_avg.clone(), self.optimizer.exp_avg_sq.clone(), self.optimizer.step_index,
@@ -163,12 +210,23 @@ class ImagePartBasedEngine:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         try:
-            with torch.cuda.stream(side):
-                for _ in range(warmup):
-                    self.forward_backward(static)
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            self.check_handovers()
+            warm_err = None
+            try:
+                with torch.cuda.stream(side):
+                    for _ in range(warmup):
+                        self.forward_backward(static)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                self.check_handovers()
+            except Exception as ex:
+                warm_err = ex
+            if agree is not None and not agree(warm_err is None):
+                # the warm-up steps hold the gradient collectives: after a failure inside one of them the ranks' collective
+                # sequences no longer match, falling back to eager is not an option
+                raise nv.NativeError('capture_step: the warm-up steps failed on %s rank: %r -- aborting the job'
+                                     % ('this' if warm_err is not None else 'another', warm_err))
+            if warm_err is not None:
+                raise warm_err
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 loss, summary = self.forward_backward(static)
@@ -187,6 +245,8 @@ class ImagePartBasedEngine:
                 self.optimizer.step_index = snap_opt[2]
                 self.optimizer.step_dev.fill_(snap_opt[2])
                 self.optimizer.updated = snap_opt[3]
+            if net is not None:
+                net.side_batch = old_batch
 
         def replay(new_data=None):
             if new_data is not None:
@@ -198,10 +258,12 @@ class ImagePartBasedEngine:
             if fused:
                 self.optimizer.sync_lr()              # scheduler changes reach the captured Adam launch through lr_dev
             graph.replay()
+            self.model.bump_param_version()          # the replayed step moved parameters and BatchNorm buffers (eval weight cache)
             if fused:
                 self.optimizer.step_index += 1       # mirrors step_dev, which the captured launch sequence increments
                 self.optimizer.updated |= captured
             self._steps += 1
+            # (every `handover_check_every` replays: the replay loop never looks at the device otherwise)
             if self.handover_check_every and self._steps % self.handover_check_every == 0:
                 self.check_handovers()
             return loss, summary
@@ -209,24 +271,40 @@ class ImagePartBasedEngine:
         self._graph = graph
         return replay
 
-    def capture_step_agreed(self, data, warmup=3):
+    def capture_step_agreed(self, data, warmup=3, side_batch=None):
         """capture_step for a data-parallel job: every rank tries to capture, then ONE MIN all-reduce of an ok flag decides for
         everybody -- all ranks replay their graphs, or all ranks launch eagerly.  (A rank replaying a graph that holds the RCCL
         launches while another one issues them eagerly is fine for RCCL, but a rank that failed to capture and silently fell back
         must not leave the others believing otherwise: the decision, and its reason, are the same on every rank.)
+        Two agreements: one after the warm-up steps (they contain the gradient collectives -- a failure there leaves the ranks'
+        collective sequences mismatched, so it aborts the job on every rank instead of falling back), one after the capture itself
+        (no collective runs while capturing: a failure there is recoverable and means eager launches for everybody).
         Returns (step(new_data=None) -> (loss, loss_summary), 'hipgraph' | 'eager', error text or None)."""
         import torch.distributed as dist
-        err, replay = None, None
+        multi = self.distributed and dist.is_initialized() and dist.get_world_size(self.process_group) > 1
+        dev = next(self.model.parameters()).device
+
+        def agree(flag):
+            ok = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+            if multi:
+                if dist.get_backend(self.process_group) != 'nccl':
+                    ok = ok.cpu()
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.process_group)
+            return int(ok.item()) == 1
+        err, replay, state = None, None, {'warm': False}
+
+        def agree_warm(flag):
+            state['warm'] = True
+            return agree(flag)
         try:
-            replay = self.capture_step(data, warmup=warmup)
-        except Exception as ex:                          # capture is an optimisation: never fatal
+            replay = self.capture_step(data, warmup=warmup, side_batch=side_batch, agree=agree_warm)
+        except Exception as ex:                          # capture is an optimisation: never fatal ...
+            if state['warm'] and 'aborting the job' in str(ex):
+                raise                                    # ... unless the warm-up steps (with their collectives) failed somewhere
             err = repr(ex)
-        ok = torch.tensor([1 if replay is not None else 0], dtype=torch.int32, device=next(self.model.parameters()).device)
-        if self.distributed and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
-            if dist.get_backend(self.process_group) != 'nccl':
-                ok = ok.cpu()
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.process_group)
-        if int(ok.item()) == 1:
+        if not state['warm']:
+            agree(True)                                  # (a capture_step that failed before its warm-up agreement: keep the sequence)
+        if agree(replay is not None):
             return replay, 'hipgraph', None
         self._graph = None
         last = {'data': data}

@@ -1,0 +1,259 @@
+"""The train step of ImagePartBasedEngine as ONE recorded launch sequence (bpbreid_amd.tape).
+
+What the engine's general path does per step through autograd -- model forward (one autograd node), GiLt's identity / triplet
+terms, the pixel CE, their weighted sum, loss.backward(), the optimizer (part_based_engine.py:77-130, GiLt_loss.py:45-119,
+part_averaged_triplet_loss.py:35-65, cross_entropy_loss.py:34-56, body_part_attention_loss.py:45-52) -- is, on a fixed batch shape
+and loss configuration, the SAME ~1150 launches on the SAME buffers every step.  FusedTrainStep runs that sequence once with every
+buffer it touches allocated for the life of the step object (no per-call torch.empty / zeros / clone / .to between the two backbone
+plans: the verdict of round 4 counted ~50 ATen fills, copies and compares there), records the library calls on a Tape while they
+execute, and from then on a step is: three boundary copies of the batch into the static input buffers, one bpb_tape_run per tape
+segment (the segments are separated by the hand-overs of gradient buckets to RCCL), and the host mirrors of what the launches did
+(Adam's step counter, the model's parameter version).  The kernels, their order and their arguments are those of the general path
+-- the same CE / triplet / pixel-CE / weighted-sum / fan-out / scale launches -- so losses, gradients and parameters are
+bit-identical to it (tests/test_gpu_fused_step.py).
+
+Not every configuration is taped; `eligible()` says why not and the engine then takes the general path:
+  * continuous (non-binary) training visibility scores WITH mask filtering (their gradients flow through autograd's accumulation),
+  * part_random_max_min_triplet_loss (draws a fresh torch.rand mask per step),
+  * a torch.optim optimizer instead of FusedAdam, a model that is not bpbreid_amd.model.BPBreID.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import torch
+
+from . import native as nv
+from .losses import _STRATEGY
+from .model import OUT_KEYS, BPBreID
+from .optim import FusedAdam
+from .tape import Tape, recording, paused
+
+GLOBAL, FOREGROUND, CONCAT_PARTS, PARTS, PIXELS = 'globl', 'foreg', 'conct', 'parts', 'pixls'
+
+
+def eligible(engine, training_binary, has_masks):
+    """None if the engine's step can be taped, otherwise the reason (a string)."""
+    m = engine.model
+    if not isinstance(m, BPBreID):
+        return 'the model is not bpbreid_amd.model.BPBreID'
+    if not isinstance(engine.optimizer, FusedAdam):
+        return 'the optimizer is not FusedAdam'
+    if engine.GiLt.use_visibility_scores and not training_binary:
+        return 'continuous training visibility scores with mask filtering'
+    if engine.GiLt.part_triplet_loss.name == 'part_random_max_min_triplet_loss':
+        return 'part_random_max_min_triplet_loss draws a fresh mask per step'
+    if not m.learnable_attention_enabled and not has_masks:
+        return 'external masks are required'
+    return None
+
+
+class FusedTrainStep:
+    def __init__(self, engine, plan, masks):
+        self.engine, self.plan = engine, plan
+        self.model = engine.model
+        dev = plan.pooled.device
+        self.dev = dev
+        self.s_masks = torch.empty_like(masks, dtype=torch.float32).contiguous() if masks is not None else None
+        self.s_pids = torch.empty(plan.N, device=dev, dtype=torch.int64)
+        self.tape = None
+        self.static = []               # every buffer the recorded launches read or write besides the plan's own
+        self.loss = None
+        self.summary = None
+        self.key = None
+
+    # ------------------------------------------------------------------ configuration the tape is valid for
+    def _key(self):
+        e, m = self.engine, self.model
+        w = e.losses_weights
+        wk = tuple((k, tuple(sorted(v.items()))) for k, v in sorted(w.items()))
+        import torch.distributed as dist
+        world = dist.get_world_size(e.process_group) if (e.distributed and dist.is_initialized()) else 0
+        return (wk, e.GiLt.use_visibility_scores, e.GiLt.part_triplet_loss.name, float(e.GiLt.part_triplet_loss.margin),
+                float(e.GiLt.part_triplet_loss.epsilon), float(e.GiLt.identity_loss.eps), float(e.body_part_attention_loss.label_smoothing),
+                bool(m.materialize_spatial_features), bool(m.training_binary_visibility_score), float(m.bn_momentum), world,
+                id(e._reducer), float(e.optimizer.weight_decay), tuple(e.optimizer.betas), float(e.optimizer.eps),
+                bool(self.plan.net.side_stream), int(self.plan.net.side_batch))
+
+    # ------------------------------------------------------------------ buffers
+    def _f(self, *shape, dtype=torch.float32):
+        t = torch.empty(*shape, device=self.dev, dtype=dtype)
+        self.static.append(t)
+        return t
+
+    # ------------------------------------------------------------------ the step
+    def __call__(self, imgs, masks, pids):
+        plan, e = self.plan, self.engine
+        plan.net.in_buf.copy_(imgs)                         # boundary copies into the static inputs (same device; H2D is the caller's)
+        if self.s_masks is not None:
+            self.s_masks.copy_(masks)
+        self.s_pids.copy_(pids)
+        opt = e.optimizer
+        opt._state()
+        if not torch.cuda.is_current_stream_capturing():
+            opt.sync_lr()
+        if e.distributed:
+            e._reducer.begin()
+        if self.tape is None or self._key() != self.key:
+            self._record()
+        else:
+            self.tape.run()
+            # host mirrors of what the replayed launches did
+            plan.generation += 1
+            plan.eval_weights_ready = False
+            self.model.bump_param_version()                 # training forward (running statistics) + optimizer step
+            opt.step_index += 1
+            opt.updated |= self._updated
+        return self.loss, self.summary
+
+    def _record(self):
+        plan, e, m = self.plan, self.engine, self.model
+        self.static = []
+        self.key = self._key()
+        tape = Tape()
+        with recording(tape):
+            outs = plan.forward(None, True, self.s_masks, static=self.static)
+            grads = self._losses(outs)
+            self._backward(grads)
+            if e.distributed:
+                red = e._reducer
+                scale = 1.0 / red.world
+
+                def finish_exchange():
+                    red.start()
+                    red.finish()
+                tape.python(finish_exchange)
+                finish_exchange()
+            else:
+                scale = 1.0
+            e.optimizer.step(grad_scale=scale)
+            self._updated = set(e.optimizer.updated)
+        tape.keep.append(self.static)
+        self.tape = tape
+
+    # ---- GiLt + pixel CE on the plan's output buffers: the launches of losses.py without the autograd glue
+    def _losses(self, outs):
+        e, plan = self.engine, self.plan
+        s = nv.stream
+        f = self._f
+        o = dict(zip(OUT_KEYS, outs))
+        n, K, D, ncls = plan.N, plan.K, plan.D, plan.ncls
+        gilt = e.GiLt
+        use_vis = gilt.use_visibility_scores
+        vis_bool = 1 if plan.binary else 0
+        # visibility rows as the losses want them (bpbreid.py:194-200 / model.pack_outputs): global = ones, foreground / concat =
+        # fgvis, parts = vis[:, 1:] (contiguous copy), as 0 / 1 floats in binary mode
+        w_rows = {}
+        if use_vis:
+            ones = f(n)
+            with paused():                                   # constants: written once, not at every replay
+                nv.call('bpb_fill', ones.data_ptr(), 1.0, n, s())
+            vparts = f(n, K)
+            nv.call('bpb_copy2d', plan.vis.data_ptr() + 4, plan.K1, vparts.data_ptr(), K, n, K, s())
+            w_rows = {GLOBAL: ones, FOREGROUND: plan.fgvis, CONCAT_PARTS: plan.fgvis, PARTS: vparts}
+        emb = {GLOBAL: (o['e_globl'], 1, D), FOREGROUND: (o['e_foreg'], 1, D), CONCAT_PARTS: (o['e_parts'], 1, K * D), PARTS: (o['e_parts'], K, D)}
+        ids = {GLOBAL: (o['s_globl'], 1), FOREGROUND: (o['s_foreg'], 1), CONCAT_PARTS: (o['s_conct'], 1), PARTS: (o['s_parts'], K)}
+        gkey_s = {GLOBAL: 's_globl', FOREGROUND: 's_foreg', CONCAT_PARTS: 's_conct', PARTS: 's_parts'}
+        gkey_e = {GLOBAL: 'e_globl', FOREGROUND: 'e_foreg', CONCAT_PARTS: 'e_parts', PARTS: 'e_parts'}
+        keys = [GLOBAL, FOREGROUND, CONCAT_PARTS, PARTS]
+        summary = {}
+        terms = []          # (weight, loss scalar tensor, backward closure(gl_ptr))
+        weights = []
+        grads = {k_: None for k_ in OUT_KEYS}
+        pids = self.s_pids
+        for key in keys:
+            info = OrderedDict()
+            w = gilt.losses_weights[key]['id']
+            if w > 0:
+                logits, div = ids[key]
+                r = n * div
+                row, dl, out = f(2, r), f(r, ncls), f(2)
+                wv = w_rows.get(key)
+                nv.call('bpb_ce_label_smooth', logits.data_ptr(), ncls, pids.data_ptr(), div, nv.ptr(wv), 1 if (wv is not None and vis_bool) else 0,
+                        r, ncls, float(gilt.identity_loss.eps), row[0].data_ptr(), row[1].data_ptr(), dl.data_ptr(), ncls, out.data_ptr(), s())
+                gbuf = f(r, ncls)
+                grads[gkey_s[key]] = gbuf.view(logits.shape)
+                terms.append((out, lambda glp, dl=dl, gbuf=gbuf: nv.call('bpb_scale', dl.data_ptr(), glp, 1.0, gbuf.data_ptr(), dl.numel(), 0, s())))
+                weights.append(w)
+                info['c'], info['a'] = out[0], out[1]
+            summary[key] = info
+        trip = gilt.part_triplet_loss
+        acc_e = {}
+        for key in keys:
+            w = gilt.losses_weights[key]['tr']
+            if w > 0:
+                x, k, d = emb[key]
+                wv = None
+                if use_vis:
+                    wv = w_rows[key]
+                dist_, pair, gsq = f(k, n, n), f(k, n, n), f(k, n, n)
+                pair_part = f(n * n + 4 * k * n, dtype=torch.int32)
+                out = f(4)
+                nv.call('bpb_part_triplet', x.data_ptr(), k * d, d, pids.data_ptr(), nv.ptr(wv), vis_bool if wv is not None else 0, None, n, k, d,
+                        _STRATEGY[trip.name], float(trip.margin), float(trip.epsilon), dist_.data_ptr(), pair.data_ptr(), pair_part.data_ptr(),
+                        gsq.data_ptr(), out.data_ptr(), None, s())
+                gk = gkey_e[key]
+                first = gk not in acc_e
+                if first:
+                    acc_e[gk] = f(n, k, d) if key != CONCAT_PARTS else f(n, K, D)
+                    grads[gk] = acc_e[gk]
+                g = acc_e[gk]
+                terms.append((out, lambda glp, x=x, k=k, d=d, gsq=gsq, g=g, acc=0 if first else 1: nv.call(
+                    'bpb_part_triplet_bwd', x.data_ptr(), k * d, d, gsq.data_ptr(), glp, 1.0, n, k, d, g.data_ptr(), k * d, d, acc, s())))
+                weights.append(w)
+                summary[key].update(t=out[0], tt=out[1], vt=out[2])
+        bpa_w = e.losses_weights[PIXELS]['ce']
+        if o['pix'] is not None and self.s_masks is not None and bpa_w > 0:
+            sc = o['pix']
+            nn_, k1, h, wd = sc.shape
+            hm, wm = self.s_masks.shape[2:]
+            ds = f(nn_, k1, h, wd)
+            nblocks = max(1, min(1024, nn_ * h * wd // 256))
+            partial = f(nblocks * 2, dtype=torch.float64)
+            out = f(2)
+            nv.call('bpb_pixel_ce', sc.data_ptr(), self.s_masks.data_ptr(), None, nn_, k1, h, wd, hm, wm, float(e.body_part_attention_loss.label_smoothing),
+                    ds.data_ptr(), partial.data_ptr(), nblocks, out.data_ptr(), s())
+            gpix = f(nn_, k1, h, wd)
+            grads['pix'] = gpix
+            terms.append((out, lambda glp, ds=ds, gpix=gpix: nv.call('bpb_scale', ds.data_ptr(), glp, 1.0, gpix.data_ptr(), ds.numel(), 0, s())))
+            weights.append(bpa_w)
+            summary[PIXELS] = OrderedDict(c=out[0], a=out[1])
+        if not terms:
+            raise nv.NativeError('FusedTrainStep: no loss term has a positive weight')
+        # weighted sum in chunks of 8 (losses.weighted_sum), then the fan-out of d loss = 1 back through the chunks
+        one = f(1)
+        with paused():
+            nv.call('bpb_fill', one.data_ptr(), 1.0, 1, s())
+        chain = []                       # (output scalar, [(weight, term out tensor | previous sum, closure | None)])
+        cur = [(w_, t_[0], t_[1]) for w_, t_ in zip(weights, terms)]
+        while True:
+            head, rest = cur[:8], cur[8:]
+            total = f(1)
+            ptrs = (C.c_void_p * len(head))(*[t_.data_ptr() for _, t_, _ in head])
+            ws = (C.c_float * len(head))(*[float(w_) for w_, _, _ in head])
+            nv.call('bpb_weighted_sum', ptrs, ws, len(head), total.data_ptr(), s())
+            chain.append((total, head, ws))
+            if not rest:
+                break
+            cur = [(1.0, total, None)] + rest
+        glp = one.data_ptr()
+        for total, head, ws in reversed(chain):
+            g = f(len(head))
+            nv.call('bpb_scalar_fanout', glp, ws, len(head), g.data_ptr(), s())
+            for i, (_, _, closure) in enumerate(head):
+                if closure is None:
+                    glp = g.data_ptr() + 4 * i               # the previous chunk's sum: its gradient feeds that chunk's fan-out
+                else:
+                    closure(g.data_ptr() + 4 * i)
+        self.loss = chain[-1][0][0]
+        self.summary = summary
+        return tuple(grads[k_] for k_ in OUT_KEYS)
+
+    def _backward(self, grads):
+        plan, e, m = self.plan, self.engine, self.model
+        m.rebind_grads()
+        if e.distributed:
+            m._bucket_hook = e._reducer
+        try:
+            plan.backward(grads, static=self.static)
+        finally:
+            m._bucket_hook = None

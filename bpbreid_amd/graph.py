@@ -218,6 +218,7 @@ class Net:
         self.bn_momentum = BN_MOMENTUM     # running-statistics momentum of every BatchNorm of this plan
         # weight-gradient launches (+ their slab reduces) of the backward plan on a second stream (csrc/plan.cpp: bpb_plan_run2)
         self.side_stream = os.environ.get('BPB_SIDE_STREAM', '1') != '0'
+        self.side_batch = int(os.environ.get('BPB_SIDE_BATCH', '1'))           # side records per fork of bpb_plan_run2 (0: one stream)
         self._side = None                  # (torch stream, fork event, join event), created on first use
 
     # ------------------------------------------------------------------ graph construction
@@ -1494,11 +1495,13 @@ class Net:
         end = n if end is None else end
         if end > begin:
             ops = C.c_void_p(C.addressof(arr) + begin * C.sizeof(PlanOp))
-            # (not under hipGraph capture: the replay of a graph with the cross-stream edges measured SLOWER than the one-stream
-            #  graph, 33.7 vs 32.8 ms per step and 21 instead of 8 ms of host time per replay, gpurun_out/r04a)
-            if self.side_stream and plan is getattr(self, 'plan_bwd', None) and not torch.cuda.is_current_stream_capturing():
+            # side_batch: side records issued per fork (1: each as soon as its inputs are final; 0: everything on the caller's
+            # stream).  A hipGraph follows the fork / join events (the side stream joins the capture and leaves it at the join), so
+            # a captured step keeps the two-stream schedule; engine.capture_step picks the batch (every cross-stream edge of a graph
+            # costs host and device time at replay: with one fork per side record the graph replayed slower than on one stream).
+            if self.side_stream and self.side_batch > 0 and plan is getattr(self, 'plan_bwd', None):
                 side, ev_fork, ev_join = self._side_objects()
-                nv.call('bpb_plan_run2', ops, end - begin, nv.stream(), C.c_void_p(side.cuda_stream), ev_fork, ev_join)
+                nv.call('bpb_plan_run2', ops, end - begin, nv.stream(), C.c_void_p(side.cuda_stream), ev_fork, ev_join, int(self.side_batch))
             else:
                 nv.call('bpb_plan_run', ops, end - begin, nv.stream())
 

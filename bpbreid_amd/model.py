@@ -156,6 +156,8 @@ class _GemmBatch:
             ws = torch.empty(max(need.value, 1 << 22), device=self.device, dtype=torch.float32)
             _ws_cache[self.device] = ws
         nv.call('bpb_gemm_grouped', self.probs, self.n, ws.data_ptr(), ws.numel(), None, nv.stream())
+        if nv._recording is not None:      # a launch tape holds the address of the descriptor array it recorded: never reuse it
+            self.probs = (nv.GemmProb * nv.GEMM_MAX)()
         self.n = 0
 
 
@@ -616,12 +618,16 @@ class _ModelPlan:
                 nv.stream())
         return self.ext_r
 
-    def forward(self, images, training, ext_masks=None):
+    def forward(self, images, training, ext_masks=None, static=None):
+        """`static` (a list): static mode of the taped train step (fused_step.FusedTrainStep) -- the caller has already put the
+        images into net.in_buf, every buffer allocated here is appended to `static` (the tape replays the launches on them) and the
+        plan's own buffers are returned instead of fresh copies; nothing but library calls happens between the launches."""
         m, net, s = self.model, self.net, nv.stream
         n, K, K1, J, HW, Cc, D, ncls = self.N, self.K, self.K1, self.J, self.HW, self.C, self.D, self.ncls
-        dev = images.device
+        dev = net.in_buf.device
         self.generation += 1
-        net.in_buf.copy_(images)                       # boundary copy (same device); H2D is the caller's business
+        if static is None:
+            net.in_buf.copy_(images)                   # boundary copy (same device); H2D is the caller's business
         x = self.feats.buf
         fresh = None
         # head on the branch outputs, the concatenated map is never written (csrc/head_lowres.hip)?
@@ -645,10 +651,11 @@ class _ModelPlan:
                 first = self.eval_param_launches()
             self.eval_weights_ready = True
             self.eval_weights_version = version
+        ibuf = m._arena['ibuf']
         if low:
             net.run(net.plan_train if training else net.plan_eval, first, lr.cut['train' if training else 'eval'])
             if training:
-                m._arena['ibuf'] += 1
+                nv.call('bpb_add_i64', ibuf.data_ptr(), ibuf.numel(), 1, s())        # every BatchNorm's num_batches_tracked
             x = None
         elif not training:
             # eval hands out a fresh feature map per call (API boundary, below): let the plan's concatenation write it directly
@@ -660,7 +667,7 @@ class _ModelPlan:
             pass
         elif training:
             net.run(net.plan_train)
-            m._arena['ibuf'] += 1                      # every BatchNorm's num_batches_tracked
+            nv.call('bpb_add_i64', ibuf.data_ptr(), ibuf.numel(), 1, s())            # every BatchNorm's num_batches_tracked
         else:
             net.run(net.plan_eval, first)
         if low or training:
@@ -729,7 +736,12 @@ class _ModelPlan:
                         self.zinv.data_ptr(), self.zinv_dl.data_ptr(), self.zinv_dx.data_ptr(), n, HW, Cc, J, s())
         # ---- after-pooling dim reduce (Linear + BN1d + ReLU); pooled rows: 0 global, 1 fg, 2 bg, 3.. parts
         o = {}
-        f = lambda *sh: _f32(*sh, device=dev)
+
+        def f(*sh):
+            t = _f32(*sh, device=dev)
+            if static is not None:
+                static.append(t)
+            return t
         pp = self.pooled.data_ptr()
         batch = _GemmBatch(dev)                          # the 3 + K Linear layers of this stage: one grouped launch
         if self.after_pooling:
@@ -746,8 +758,11 @@ class _ModelPlan:
             o['p'] = f(n, K, D)
             self.dr_p_bn.fwd(self.lin_p.data_ptr(), D, n * K, o['p'].data_ptr(), D, training)
         else:                                          # the pooled rows are the embeddings (bpbreid.py:205-209 skipped)
-            o['g'], o['f'], o['b'] = (self.pooled[:, r].clone() for r in (0, 1, 2))
-            o['p'] = self.pooled[:, 3:].clone()
+            for key, r in (('g', 0), ('f', 1), ('b', 2)):
+                o[key] = f(n, Cc)
+                nv.call('bpb_copy2d', pp + r * Cc * 4, J * Cc, o[key].data_ptr(), Cc, n, Cc, s())
+            o['p'] = f(n, K, Cc)
+            nv.call('bpb_copy2d', pp + 3 * Cc * 4, J * Cc, o['p'].data_ptr(), K * Cc, n, K * Cc, s())
         # ---- BN-neck identity classifiers: every BatchNorm1d first, then the 4 + K (or 5) Linear layers as one grouped launch
         e = {}
         for key, src, width in (('g', o['g'], D), ('b', o['b'], D), ('f', o['f'], D), ('c', o['p'], K * D)):
@@ -772,6 +787,9 @@ class _ModelPlan:
         # (the reference engine collects pixels_cls_scores / masks of every test batch, part_based_engine.py:141-157).  The
         # 1 GB feature map is the exception in TRAINING mode: it is returned as a logical-NCHW view of the NHWC plan buffer,
         # valid until the next forward of this shape.
+        if static is not None:     # taped step: the plan's own buffers (the tape's launches write them again at every replay)
+            return (o['g'], o['b'], o['f'], o['p'], e['g'][0], e['b'][0], e['f'][0], e['c'][0], bn_p,
+                    e['g'][1], e['b'][1], e['f'][1], e['c'][1], s_p, self.scores if self.learnable else None, None, self.vis, self.fgvis)
         pix = self.scores.clone() if self.learnable else torch.empty(0, device=dev)
         feats_nchw = x.permute(0, 3, 1, 2) if x is not None else torch.empty(0, device=dev)      # (not materialised: None outside)
         # visibility scores as outputs of the autograd node: continuous scores are differentiable (the reference back-propagates
@@ -801,13 +819,18 @@ class _ModelPlan:
         return emb, visd, ids, (pix if self.learnable else None), (None if self.low else feats), masks
 
     # ---------------------------------------------------------------- backward
-    def backward(self, grads):
-        """grads: tuple aligned with OUT_KEYS (None where no gradient flows)."""
+    def backward(self, grads, static=None):
+        """grads: tuple aligned with OUT_KEYS (None where no gradient flows).  `static`: static mode of the taped step, as in forward."""
         m, net, s = self.model, self.net, nv.stream
         n, K, K1, J, HW, Cc, D, ncls = self.N, self.K, self.K1, self.J, self.HW, self.C, self.D, self.ncls
         dev = self.pooled.device
         g = dict(zip(OUT_KEYS, grads))
-        f = lambda *sh: _f32(*sh, device=dev)
+
+        def f(*sh):
+            t = _f32(*sh, device=dev)
+            if static is not None:
+                static.append(t)
+            return t
 
         def init_grad(ext, *shape):
             buf = f(*shape)
@@ -875,9 +898,9 @@ class _ModelPlan:
         if not self.after_pooling:                     # the embeddings ARE the pooled rows: strided row copies (plumbing)
             for key, row in (('g', 0), ('f', 1), ('b', 2)):
                 if has[key]:
-                    gpool[:, row].copy_(d_o[key])
+                    nv.call('bpb_copy2d', d_o[key].data_ptr(), Cc, gp_ptr + row * Cc * 4, J * Cc, n, Cc, s())
             if has['p']:
-                gpool[:, 3:].copy_(d_o['p'])
+                nv.call('bpb_copy2d', d_o['p'].data_ptr(), K * Cc, gp_ptr + 3 * Cc * 4, J * Cc, n, K * Cc, s())
         else:
             dlins = []
             for key, row in (('g', 0), ('f', 1), ('b', 2)):
@@ -988,7 +1011,10 @@ class _ModelPlan:
                 if idx >= 0 and idx + 1 > pos:
                     net.run(net.plan_bwd, pos, idx + 1)
                     pos = idx + 1
-                hook.ready(buckets, early=idx + 1 < net.plan_bwd[1])
+                early = idx + 1 < net.plan_bwd[1]
+                if nv._recording is not None:         # taped step: the hand-over is a host action between two tape segments
+                    nv._recording.python(lambda b_=buckets, e_=early: hook.ready(b_, early=e_))
+                hook.ready(buckets, early=early)
             net.run(net.plan_bwd, pos)
         self.touched |= self.backbone_touched
         for p in m._arena['params']:          # parameters that did not take part keep grad None (torch semantics)

@@ -652,12 +652,39 @@ int bpb_plan_run(const BpbPlanOp* ops, int nops, hipStream_t stream);
 /* the same walk over two streams: records with i[10] == 1 (weight gradients, slab reduces, bias sums: nothing on the plan reads
  * their results) go to `side`, forked from / joined into `main` with the caller's two events; side == NULL = bpb_plan_run.
  * Replaces what autograd's engine does for hrnet.py:532-576 backward (independent weight / data gradients of one layer). */
-int bpb_plan_run2(const BpbPlanOp* ops, int nops, hipStream_t main, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join);
+int bpb_plan_run2(const BpbPlanOp* ops, int nops, hipStream_t main, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join,
+                  int side_batch);   /* side_batch: side records issued per fork (1: as soon as their inputs are final) */
 /* events for bpb_plan_run2 (timing disabled); owned by the caller */
 int bpb_event_create(hipEvent_t* out);
 int bpb_event_destroy(hipEvent_t ev);
 /* measurement only: per-op elapsed milliseconds via HIP events on `stream` (synchronises) */
 int bpb_plan_run_timed(const BpbPlanOp* ops, int nops, hipStream_t stream, float* ms_out);
+
+/* ---- launch tape (csrc/tape.cpp): a recorded sequence of calls of THIS header's stream-taking entry points, replayed by one
+   host call -- the head / loss / optimizer stretch of a train step (torchreid/engine/image/part_based_engine.py:77-130,
+   torchreid/losses/GiLt_loss.py:45-119 run it as Python).  An argument travels as one 8-byte word. */
+#define BPB_TAPE_MAX_ARGS 24
+typedef union {
+    void* p;
+    long l;
+    int i;
+    float f;
+    double d;
+} BpbTapeArg;
+typedef struct {
+    int fn;                    /* bpb_tape_function(name) */
+    int nargs;
+    unsigned stream_mask;      /* bit q set: argument q is replaced by the stream bpb_tape_run is called with */
+    int pad_;
+    BpbTapeArg a[BPB_TAPE_MAX_ARGS];
+} BpbTapeOp;
+int bpb_tape_function(const char* name);                 /* index of a tapeable entry point, -1 if it is not one */
+int bpb_tape_signature(int fn, char* out);               /* parameter kinds as compiled: p i l f d, s = hipStream_t; returns the count */
+int bpb_tape_run(const BpbTapeOp* ops, int nops, hipStream_t stream);
+/* plumbing of the taped step: x[0..n) += v (BatchNorm num_batches_tracked, nn.BatchNorm2d training semantics) and a strided
+   2-D float copy dst[r][c] = src[r][c] (rows x cols, row pitches in elements) */
+int bpb_add_i64(long* x, long n, long v, hipStream_t stream);
+int bpb_copy2d(const float* src, long lds, float* dst, long ldd, int rows, int cols, hipStream_t stream);
 
 #ifdef __cplusplus
 }

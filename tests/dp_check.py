@@ -60,7 +60,8 @@ def main():
 
     eng = engine(True)
     p0 = arena['param'].clone()
-    eng.forward_backward(batch(rank))
+    eng.forward_backward(batch(rank))         # records the step's launch tape (bucket hand-overs between its segments) ...
+    eng.forward_backward(batch(rank))         # ... and replays it: the learning rate is 0, the gradients must be the same again
     torch.cuda.synchronize()
     g_dp = arena['grad'].clone()
     red = eng._reducer

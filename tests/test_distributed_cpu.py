@@ -151,3 +151,77 @@ def test_all_gather_cat_ragged_world2():
     for _, rows, cols, ids, empty, contiguous in res:
         assert (rows == full).all() and (cols == full.transpose(1, 0, 2)).all() and contiguous
         assert ids.tolist() == list(range(7)) and (empty == full[:2]).all()
+
+
+class _StubModel(torch.nn.Module):
+    parts_num = 2
+
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.zeros(1))
+
+
+def _agree_worker(rank, world, port, q):
+    """capture_step_agreed with the capture itself stubbed: the decision protocol (collectives on gloo) is what is tested."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from bpbreid_amd.engine import ImagePartBasedEngine
+    from bpbreid_amd import native as nv
+    eng = ImagePartBasedEngine(_StubModel(), distributed=True)
+    out = {}
+    eng.forward_backward = lambda data: ('eager-loss', {})
+    # (1) the capture fails on rank 1 only -> eager on BOTH ranks, each with a reason
+    def capture_fails_on_rank1(data, warmup=3, side_batch=None, agree=None):
+        assert agree(True)                                  # the warm-up steps went through everywhere
+        if rank == 1:
+            raise RuntimeError('simulated capture failure on rank 1')
+        return lambda new_data=None: ('graph-loss', {})
+    eng.capture_step = capture_fails_on_rank1
+    step, mode, why = eng.capture_step_agreed({'x': 1})
+    out['one_fails'] = (mode, why, step()[0])
+    # (2) everybody captures -> graph on both
+    eng.capture_step = lambda data, warmup=3, side_batch=None, agree=None: (agree(True), (lambda new_data=None: ('graph-loss', {})))[1]
+    step, mode, why = eng.capture_step_agreed({'x': 1})
+    out['all_ok'] = (mode, why, step()[0])
+    # (3) a stub that never reaches the warm-up agreement on one rank (fails before it) keeps the collective sequence matched
+    def early_failure_on_rank0(data, warmup=3, side_batch=None, agree=None):
+        if rank == 0:
+            raise RuntimeError('simulated early failure')
+        return lambda new_data=None: ('graph-loss', {})
+    eng.capture_step = early_failure_on_rank0
+    step, mode, why = eng.capture_step_agreed({'x': 1})
+    out['early'] = (mode, why, step()[0])
+    # (4) the warm-up steps (which hold the gradient collectives) fail on rank 1 -> the job is aborted on BOTH ranks
+    def warmup_fails_on_rank1(data, warmup=3, side_batch=None, agree=None):
+        if not agree(rank != 1):
+            raise nv.NativeError('capture_step: the warm-up steps failed on %s rank -- aborting the job' % ('this' if rank == 1 else 'another'))
+        return lambda new_data=None: ('graph-loss', {})
+    eng.capture_step = warmup_fails_on_rank1
+    try:
+        eng.capture_step_agreed({'x': 1})
+        out['warmup'] = 'returned'
+    except nv.NativeError as ex:
+        out['warmup'] = str(ex)
+    dist.barrier()                                            # the collective sequences of the two ranks still match
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_capture_step_agreed_decides_once_for_all_ranks_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agree_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    r0, r1 = res[0], res[1]
+    assert r0['one_fails'][0] == r1['one_fails'][0] == 'eager' and r0['one_fails'][2] == r1['one_fails'][2] == 'eager-loss'
+    assert 'another rank' in r0['one_fails'][1] and 'simulated capture failure on rank 1' in r1['one_fails'][1]
+    assert r0['all_ok'] == r1['all_ok'] == ('hipgraph', None, 'graph-loss')
+    assert r0['early'][0] == r1['early'][0] == 'eager' and 'simulated early failure' in r0['early'][1]
+    assert 'aborting the job' in r0['warmup'] and 'aborting the job' in r1['warmup']

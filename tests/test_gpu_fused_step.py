@@ -1,0 +1,173 @@
+"""GPU tests of the taped train step (bpbreid_amd/fused_step.py, bpbreid_amd/tape.py, csrc/tape.cpp): the engine's step recorded once
+and replayed by bpb_tape_run must equal the general path (autograd.Function glue around the same kernels) BIT FOR BIT -- losses,
+summaries, gradient arena, parameters, BatchNorm buffers, Adam state -- over several steps, for every loss configuration it accepts;
+configurations it does not accept must take the general path and say why.
+Reference semantics: torchreid/engine/image/part_based_engine.py:77-130 (forward_backward + combine_losses), GiLt_loss.py:45-119."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import common as Cm                                            # noqa: E402
+from bpbreid_amd.model import bpbreid                         # noqa: E402
+from bpbreid_amd.engine import ImagePartBasedEngine           # noqa: E402
+from bpbreid_amd.optim import FusedAdam                       # noqa: E402
+
+DEV = torch.device('cuda', 0)
+W_DEFAULT = {'globl': {'id': 1., 'tr': 0.}, 'foreg': {'id': 1., 'tr': 0.}, 'conct': {'id': 1., 'tr': 0.},
+             'parts': {'id': 0., 'tr': 1.}, 'pixls': {'ce': 0.35}}
+W_ALL = {'globl': {'id': 1., 'tr': 0.5}, 'foreg': {'id': 0.7, 'tr': 1.}, 'conct': {'id': 1., 'tr': 0.25},
+         'parts': {'id': 0.3, 'tr': 1.}, 'pixls': {'ce': 0.35}}          # 9 terms: the weighted sum runs in two chunks
+
+
+def _run(backbone, weights, fused, steps=4, filtering=True, loss_name='part_averaged_triplet_loss', with_masks=True, cfg_edit=None,
+         k=3, d=64, n=8, h=128, w=64, ncls=16):
+    cfg = Cm.make_cfg(backbone, k, d)
+    if cfg_edit:
+        cfg_edit(cfg)
+    imgs, masks, pids = Cm.synth_batch(n, h, w, k, ncls)
+    model = Cm.fill_state_dict_(bpbreid(ncls, config=cfg, pretrained=False)).to(DEV)
+    eng = ImagePartBasedEngine(model, optimizer=FusedAdam(model, lr=1e-3, weight_decay=5e-4), losses_weights=weights,
+                               mask_filtering_training=filtering, loss_name=loss_name)
+    eng.fused_step = fused
+    out = []
+    for it in range(steps):
+        g = torch.Generator().manual_seed(100 + it)
+        perm = torch.randperm(n, generator=g)                  # a different batch every step: the static input buffers are refilled
+        data = {'image': imgs[perm].to(DEV), 'pid': pids[perm].to(DEV)}
+        if with_masks:
+            data['mask'] = masks[perm].to(DEV)
+        loss, summ = eng.forward_backward(data)
+        flat = {'%s.%s' % (a, b): float(v) for a, dd in summ.items() for b, v in dd.items()}
+        out.append((float(loss), flat, model.arena()['grad'].clone(), [p.grad is None for p in model.parameters()]))
+    torch.cuda.synchronize()
+    a = model.arena()
+    state = (a['param'].clone(), a['fbuf'].clone(), a['ibuf'].clone(), eng.optimizer.exp_avg.clone(), eng.optimizer.exp_avg_sq.clone(),
+             eng.optimizer.step_index, int(eng.optimizer.step_dev.item()), sorted(eng.optimizer.updated))
+    return out, state, eng
+
+
+def _assert_same(a, b):
+    (oa, sa, _), (ob, sb, _) = a, b
+    for (la, fa, ga, na), (lb, fb, gb, nb) in zip(oa, ob):
+        assert la == lb and fa == fb and na == nb
+        assert torch.equal(ga, gb)
+    for x, y in zip(sa, sb):
+        assert torch.equal(x, y) if torch.is_tensor(x) else x == y
+
+
+@pytest.mark.parametrize('backbone,weights', [('hrnet_w16', W_DEFAULT), ('hrnet_w16', W_ALL), ('resnet50', W_ALL)])
+def test_taped_step_is_bit_identical_to_the_general_path(backbone, weights):
+    ref = _run(backbone, weights, fused=False)
+    got = _run(backbone, weights, fused=True)
+    eng = got[2]
+    assert eng.fused_reason is None and len(eng._fused) == 1
+    step = next(iter(eng._fused.values()))
+    assert step.tape is not None and step.tape.launch_calls > 40
+    _assert_same(ref, got)
+
+
+@pytest.mark.parametrize('case', ['no_filtering', 'no_masks', 'nolearn', 'no_after_pooling', 'max_min', 'shared_cls'])
+def test_taped_step_variants(case):
+    kw = {}
+    if case == 'no_filtering':
+        kw = dict(filtering=False)
+    elif case == 'no_masks':                                   # no pixel CE, attention learned without supervision
+        kw = dict(with_masks=False)
+    elif case == 'nolearn':
+        kw = dict(cfg_edit=lambda c: setattr(c.model.bpbreid, 'learnable_attention_enabled', False))
+    elif case == 'no_after_pooling':
+        kw = dict(cfg_edit=lambda c: setattr(c.model.bpbreid, 'dim_reduce', 'before_pooling'))
+    elif case == 'max_min':
+        kw = dict(loss_name='part_max_min_triplet_loss')
+    elif case == 'shared_cls':
+        kw = dict(cfg_edit=lambda c: setattr(c.model.bpbreid, 'shared_parts_id_classifier', True))
+    ref = _run('hrnet_w8', W_ALL, fused=False, h=64, w=32, **kw)
+    got = _run('hrnet_w8', W_ALL, fused=True, h=64, w=32, **kw)
+    assert got[2].fused_reason is None
+    _assert_same(ref, got)
+
+
+def test_configurations_the_tape_does_not_cover_take_the_general_path():
+    out, _, eng = _run('hrnet_w8', W_DEFAULT, fused=True, steps=2, h=64, w=32, loss_name='part_random_max_min_triplet_loss')
+    assert 'fresh mask' in eng.fused_reason and not eng._fused and all(torch.isfinite(torch.tensor(o[0])) for o in out)
+    out, _, eng = _run('hrnet_w8', W_DEFAULT, fused=True, steps=2, h=64, w=32,
+                       cfg_edit=lambda c: setattr(c.model.bpbreid, 'training_binary_visibility_score', False))
+    assert 'continuous' in eng.fused_reason and not eng._fused
+    # ... and without mask filtering the continuous scores are constants for the losses: taped
+    out, _, eng = _run('hrnet_w8', W_DEFAULT, fused=True, steps=2, h=64, w=32, filtering=False,
+                       cfg_edit=lambda c: setattr(c.model.bpbreid, 'training_binary_visibility_score', False))
+    assert eng.fused_reason is None and eng._fused
+
+
+def test_a_changed_loss_configuration_re_records_the_tape():
+    cfg = Cm.make_cfg('hrnet_w8', 3, 64)
+    imgs, masks, pids = Cm.synth_batch(8, 64, 32, 3, 16)
+    data = {'image': imgs.to(DEV), 'mask': masks.to(DEV), 'pid': pids.to(DEV)}
+
+    def run(fused):
+        model = Cm.fill_state_dict_(bpbreid(16, config=cfg, pretrained=False)).to(DEV)
+        eng = ImagePartBasedEngine(model, optimizer=FusedAdam(model, lr=1e-3), losses_weights={k_: dict(v) for k_, v in W_DEFAULT.items()},
+                                   mask_filtering_training=True)
+        eng.fused_step = fused
+        losses = []
+        for it in range(4):
+            if it == 2:
+                eng.losses_weights['foreg']['tr'] = 1.0          # mid-run change of the objective
+                eng.GiLt.losses_weights = eng.losses_weights
+            losses.append(float(eng.forward_backward(data)[0]))
+        return losses, model.arena()['param'].clone(), eng
+    l0, p0, _ = run(False)
+    l1, p1, eng = run(True)
+    assert l0 == l1 and torch.equal(p0, p1)
+    assert 't' in eng.forward_backward(data)[1]['foreg']
+
+
+@pytest.mark.parametrize('side_batch', [0, 1, 8])
+def test_captured_taped_step_keeps_the_two_stream_schedule_and_the_trajectory(side_batch):
+    """engine.capture_step on the taped step: the replayed tape is captured into the hipGraph, with the weight gradients of the
+    backward plan on the side stream (side_batch >= 1: the capture follows bpb_plan_run2's fork / join events) or on one stream
+    (0).  The trajectory must equal the eager one bit for bit in every form."""
+    cfg = Cm.make_cfg('hrnet_w8', 3, 64)
+    imgs, masks, pids = Cm.synth_batch(8, 64, 32, 3, 16)
+    data = {'image': imgs.to(DEV), 'mask': masks.to(DEV), 'pid': pids.to(DEV)}
+
+    def run(graph):
+        model = Cm.fill_state_dict_(bpbreid(16, config=cfg, pretrained=False)).to(DEV)
+        eng = ImagePartBasedEngine(model, optimizer=FusedAdam(model, lr=1e-3), losses_weights=W_DEFAULT, mask_filtering_training=True)
+        if graph:
+            step, mode, why = eng.capture_step_agreed(data, warmup=2, side_batch=side_batch)
+            assert mode == 'hipgraph' and why is None, why
+            net = next(iter(model._plans.values())).net
+            assert net.side_batch == 1                              # the eager default is back after the capture
+        else:
+            step = lambda: eng.forward_backward(data)
+        out = [float(step()[0]) for _ in range(3)]
+        torch.cuda.synchronize()
+        return out, model.arena()['param'].clone(), model
+    l0, p0, _ = run(False)
+    l1, p1, model = run(True)
+    assert l0 == l1 and torch.equal(p0, p1)
+
+
+def test_graph_replay_advances_the_parameter_version_for_the_eval_weight_cache():
+    cfg = Cm.make_cfg('hrnet_w8', 3, 64)
+    imgs, masks, pids = Cm.synth_batch(8, 64, 32, 3, 16)
+    data = {'image': imgs.to(DEV), 'mask': masks.to(DEV), 'pid': pids.to(DEV)}
+    model = Cm.fill_state_dict_(bpbreid(16, config=cfg, pretrained=False)).to(DEV)
+    eng = ImagePartBasedEngine(model, optimizer=FusedAdam(model, lr=1e-2), losses_weights=W_DEFAULT, mask_filtering_training=True)
+    replay = eng.capture_step(data, warmup=2)
+    model.eval()
+    with torch.no_grad(), model.eval_weights_cached():
+        a = model(data['image'], external_parts_masks=data['mask'])[0]['bn_foreg'].clone()
+        model.train()
+        v = model._param_version
+        replay()
+        assert model._param_version > v
+        model.eval()
+        b = model(data['image'], external_parts_masks=data['mask'])[0]['bn_foreg'].clone()
+    with torch.no_grad():
+        c = model(data['image'], external_parts_masks=data['mask'])[0]['bn_foreg'].clone()      # outside the cache: always re-derived
+    assert torch.equal(b, c) and not torch.equal(a, b)

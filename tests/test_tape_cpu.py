@@ -1,0 +1,102 @@
+"""CPU tests of the launch tape (bpbreid_amd/tape.py, csrc/tape.cpp): the thunk table against the header and the ctypes prototypes,
+the recorder's argument conversion, replay order with host actions between the segments.  No kernel is launched: the recorded calls
+are ones whose argument checks fail before the launch, so the return code and bpb_last_error() show what arrived on the C side."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from bpbreid_amd import native as nv
+from bpbreid_amd.tape import Tape, recording, paused
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declarations():
+    header = open(os.path.join(ROOT, 'include', 'bpbreid_hip.h')).read()
+    return re.findall(r'^\s*int\s+(bpb_\w+)\s*\(([^;]*?)\)\s*;', header, flags=re.M | re.S)
+
+
+def test_every_stream_taking_entry_point_is_tapeable_with_its_compiled_signature():
+    lib = nv.lib()
+    decls = _declarations()
+    assert len(decls) > 80
+    buf = C.create_string_buffer(nv.TAPE_MAX_ARGS + 1)
+    seen = 0
+    for name, params in decls:
+        fn = lib.bpb_tape_function(name.encode())
+        if 'hipStream_t' not in params or name in ('bpb_plan_run_timed', 'bpb_tape_run'):
+            assert fn == -1, name               # (the measurement variant synchronises, a tape does not hold tapes: never taped)
+            continue
+        assert fn >= 0, '%s takes a stream but is not in BPB_TAPE_FUNCTIONS (csrc/tape.cpp)' % name
+        n = lib.bpb_tape_signature(fn, buf)
+        sig = buf.value.decode()
+        params = re.sub(r'/\*.*?\*/', '', params, flags=re.S)
+        assert n == len(sig) == len([p for p in params.split(',') if p.strip()]), name
+        assert sig.count('s') == params.count('hipStream_t'), name
+        # the hand-written ctypes prototype of native.py must agree with what the compiler saw (streams are pointers there)
+        assert nv.PROTOS[name] == sig.replace('s', 'p'), (name, nv.PROTOS[name], sig)
+        seen += 1
+    assert seen >= 79
+    assert lib.bpb_tape_function(b'bpb_no_such_entry') == -1 and lib.bpb_tape_signature(-1, buf) == -1
+
+
+def test_recorder_converts_arguments_and_replay_keeps_order_and_reports_errors():
+    lib = nv.lib()
+    tape = Tape()
+    order = []
+    s = nv.StreamArg(0x1234)
+    w = (C.c_float * 9)(*range(9))
+    ptrs = (C.c_void_p * 9)()
+    with recording(tape):
+        assert nv._recording is tape
+        with pytest.raises(nv.NativeError, match=r'bpb_weighted_sum: 9 terms'):        # the call runs (and fails) while it is recorded
+            nv.call('bpb_weighted_sum', ptrs, w, 9, None, s)
+        tape.python(lambda: order.append('between'))
+        with pytest.raises(nv.NativeError, match='bpb_copy2d: bad arguments'):
+            nv.call('bpb_copy2d', 16, 3, None, 5, 2, 4, s)
+        with paused():
+            with pytest.raises(nv.NativeError):
+                nv.call('bpb_copy2d', 16, 3, None, 5, 2, 4, s)                           # executed, not recorded
+        need = C.c_long(0)
+        nv.call('bpb_argsort_rows_gpu_workspace', 4, 100, C.byref(need))                # no stream argument: not a launch, not recorded
+        assert need.value > 0
+    assert nv._recording is None
+    assert [k for k, *_ in tape.items] == ['ops', 'py', 'ops'] and tape.launch_calls == 2
+    op = tape.items[0][1][0]
+    assert op.nargs == 5 and op.stream_mask == 1 << 4 and op.a[2].i == 9 and op.a[0].p == C.addressof(ptrs) and op.a[1].p == C.addressof(w)
+    op2 = tape.items[2][1][0]
+    assert op2.stream_mask == 1 << 6 and (op2.a[0].p, op2.a[1].l, op2.a[2].p, op2.a[3].l, op2.a[4].i, op2.a[5].i) == (16, 3, None, 5, 2, 4)
+    # replay of the first segment alone: the C side sees n = 9 again and refuses before any launch
+    rc = lib.bpb_tape_run(tape.items[0][1], 1, None)
+    assert rc == -1 and b'9 terms' in lib.bpb_last_error()
+    with pytest.raises(nv.NativeError, match='9 terms'):
+        import torch
+        if not torch.cuda.is_available():
+            # Tape.run asks torch for the current stream: give it one without a GPU
+            import unittest.mock as mock
+            with mock.patch.object(nv, 'stream', lambda: nv.StreamArg(0)):
+                tape.run()
+        else:
+            tape.run()
+    assert order == []                                                                    # the failing first segment stops the replay
+    assert lib.bpb_tape_run(None, 0, None) == 0
+    bad = (nv.TapeOp * 1)()
+    bad[0].fn = 10 ** 6
+    assert lib.bpb_tape_run(bad, 1, None) == -1 and b'bad entry' in lib.bpb_last_error()
+
+
+def test_recorder_refuses_what_it_cannot_replay():
+    tape = Tape()
+    with pytest.raises(nv.NativeError, match='cannot be recorded'):
+        tape.record('bpb_plan_run_timed', (None, 0, nv.StreamArg(0), None))
+    with pytest.raises(nv.NativeError, match='cannot be recorded'):
+        tape.record('bpb_fill', (object(), 0.0, 1, nv.StreamArg(0)))
+    with pytest.raises(nv.NativeError, match='takes 4 arguments'):
+        tape.record('bpb_fill', (None, 0.0, nv.StreamArg(0)))
+    t2 = Tape()
+    with recording(t2):
+        with pytest.raises(nv.NativeError, match='already recording'):
+            with recording(Tape()):
+                pass
