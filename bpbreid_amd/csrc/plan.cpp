@@ -143,6 +143,9 @@ static int run_one(const BpbPlanOp& o, int k, hipStream_t stream)
             case BPB_OP_CONV_S1:   // p0 device probs, p1 host probs, i0 nprobs
                 rc = bpb_conv_s1((const BpbConvS1Prob*)o.p[0], (const BpbConvS1Prob*)o.p[1], o.i[0], stream);
                 break;
+            case BPB_OP_CONV_PW:   // p0 device probs, p1 host probs, i0 nprobs
+                rc = bpb_conv_pw((const BpbConvPwProb*)o.p[0], (const BpbConvPwProb*)o.p[1], o.i[0], stream);
+                break;
             case BPB_OP_CONV_S1W:   // p0 device probs, p1 host probs, i0 nprobs
                 rc = bpb_conv_s1w((const BpbConvS1wProb*)o.p[0], (const BpbConvS1wProb*)o.p[1], o.i[0], stream);
                 break;

@@ -26,7 +26,7 @@ import os
 import torch
 
 from . import native as nv
-from .native import (BnEvalDesc, ConvProb, ConvS1Prob, ConvS1wProb, WgradProb, PackProb, FuseArgs, TermBwdArgs, BilinearArgs, BnFinDesc,
+from .native import (BnEvalDesc, ConvProb, ConvS1Prob, ConvS1wProb, ConvPwProb, WgradProb, PackProb, FuseArgs, TermBwdArgs, BilinearArgs, BnFinDesc,
                      BnBwdFinDesc, WgradReduceDesc, BilinearBwdDesc, Wgrad1x1Prob, PlanOp, magic)
 
 OP_NONE = -1                 # placeholder record: takes part in the lock-step merge, is never launched
@@ -208,6 +208,9 @@ class Net:
         self.merge_identity = os.environ.get('BPB_MERGE_IDENTITY', '1') != '0'
         self.fold_eval_bn = os.environ.get('BPB_FOLD_EVAL_BN', '1') != '0'
         self.dgrad_bn_partials = os.environ.get('BPB_DGRAD_BN', '1') != '0'    # BatchNorm-backward partials from the dgrad epilogue
+        self.use_pw = os.environ.get('BPB_CONV_PW', '1') != '0'                # 0: pointwise convolutions with K <= 256 on bpb_conv_s1 instead of bpb_conv_pw
+        self.debug_pw = []
+        self.pw_min_pixels = 8192      # fewer pixels: not enough 32-pixel tiles for a one-generation persistent grid (tests lower it)
         self.use_s1w = os.environ.get('BPB_CONV_S1W', '1') != '0'              # 0: strided 3x3 data gradients on the general kernel
         self.use_s1_1x1s2 = os.environ.get('BPB_S1_1X1_STRIDE2', '1') != '0'    # 0: data gradient of 1x1 stride-2 convolutions as parity classes of the general kernel
         self.use_conv_c4 = os.environ.get('BPB_CONV_C4', '1') != '0'             # 0: stem forward on the general kernel
@@ -351,6 +354,10 @@ class Net:
         n, hi, wi = x_dims
         h, w = (hi + 2 * (r // 2) - r) // stride + 1, (wi + 2 * (r // 2) - r) // stride + 1
         t = r * r
+        if r == 1 and stride == 1 and not in_region and self.use_pw and getattr(self, 'force_tile', None) is None:
+            pw = self.pw_problem(x_buf, n * h * w, w_packed, y_buf, cin, cout, bias=bias, stats=stats, accumulate=accumulate, relu=relu)
+            if pw is not None:
+                return pw
         k2 = t * cin // 2                                  # MFMAs per 32x32 wave tile
         # wave tile (mt x 32 pixels) x (nt x 32 channels): enough MFMAs per workgroup to amortise its prologue / epilogue
         # (~600 instructions), few enough that the deep low-resolution branches still split into many workgroups
@@ -470,6 +477,44 @@ class Net:
             p.stats = st_buf.data_ptr()
             stats.append(st_buf)
         self.debug_convs.append((p, x_buf, w_packed, y_buf))
+        return p
+
+    def pw_problem(self, x_buf, npix, w_packed, y_buf, cin, cout, bias=None, stats=None, accumulate=0, relu=0):
+        """One ConvPwProb (csrc/conv_pw.hip): y[P, cout] = x[P, cin] . W for a stand-alone 1x1 stride-1 convolution with K <= 256 --
+        persistent workgroups with their weight slice resident in LDS, autonomous waves.  None where the kernel does not apply
+        (K > 256: the slice of 64 output channels no longer fits half a CU's LDS; few pixels: not enough 32-pixel tiles to give
+        every wave of a one-generation grid work) -- bpb_conv_s1 takes those."""
+        if cin not in (64, 128, 192, 256) or cout % 64 or cout > 1024 or npix < self.pw_min_pixels:
+            return None
+        # Cin == 64: the A registers of a tile serve every 64-channel pass -> the widest column block whose weights fit (x read once);
+        # Cin > 64: one 64-channel pass per workgroup, the column blocks of a pixel group share an XCD's L2 (xr)
+        ntc = 64
+        if cin == 64:
+            for c_ in (256, 128):
+                if cout % c_ == 0:
+                    ntc = c_
+                    break
+        n_nt = cout // ntc
+        if n_nt & (n_nt - 1) or n_nt > 4:
+            return None
+        lds = cin * ntc * 4 + 4 * ntc * 16
+        per_cu = max(1, min(2, (160 * 1024) // lds))          # ~195 VGPRs: two workgroups (eight waves) per CU
+        tiles = _cdiv(npix, 32)
+        p = ConvPwProb()
+        p.x, p.w, p.y = x_buf.data_ptr(), w_packed.data_ptr(), y_buf.data_ptr()
+        p.bias = bias.data_ptr() if bias is not None else None
+        p.stats = None
+        p.P, p.Cin, p.Cout, p.NTC, p.l_ntiles = npix, cin, cout, ntc, _log2(n_nt)
+        p.n_mtiles = max(1, min(_cdiv(tiles, 4), (256 * per_cu) // n_nt))
+        p.ntiles32 = tiles
+        p.blk_begin, p.accumulate, p.relu = 0, accumulate, relu
+        p.xr = 1 if os.environ.get('BPB_XCD_MAP', '1') != '0' else 0
+        p.x_bytes, p.w_bytes, p.y_bytes = x_buf.numel() * 4, w_packed.numel() * 4, y_buf.numel() * 4
+        if stats is not None:
+            st_buf = torch.empty(p.n_mtiles * 2 * cout, device=self.device, dtype=torch.float64)
+            p.stats = st_buf.data_ptr()
+            stats.append(st_buf)
+        self.debug_pw.append((p, x_buf, w_packed, y_buf))
         return p
 
     def s1w_problem(self, dy_buf, dy_dims, w_packed, dx_buf, dx_hw, cin, cout, accumulate):
@@ -617,6 +662,11 @@ class Net:
 
     def _conv_rec(self, prob, label):
         """Launch record of one convolution problem (either kernel)."""
+        if isinstance(prob, ConvPwProb):
+            flops = 2.0 * prob.P * prob.Cin * prob.Cout
+            return Rec(nv.OP_CONV_PW, '%s bpb_conv_pw_kernel<%s>' % (label, 'true' if prob.Cin == 64 else 'false'), flops,
+                       4.0 * prob.P * (prob.Cin + prob.Cout), desc=prob, key=('pw', prob.Cin == 64), blocks=prob.n_mtiles << prob.l_ntiles,
+                       work=float(prob.Cin * (prob.NTC // 32)))
         if isinstance(prob, ConvS1Prob):
             kind, key = nv.OP_CONV_S1, ('s1', prob.nt, prob.mt_r, prob.R, prob.CK)
             variant = 'bpb_conv_s1_kernel<%d,%d,%d,%d>' % (prob.nt, prob.mt_r, prob.R, prob.CK // 8)
@@ -761,7 +811,7 @@ class Net:
                         prob_eval.w = cv.wf_eval.data_ptr()
                         prob_eval.bias = bn.shift.data_ptr()
                         sink = eval_sink.get(id(cv))
-                        if sink is not None and sink[2] is not None and not isinstance(prob_eval, ConvS1Prob):
+                        if sink is not None and sink[2] is not None and not isinstance(prob_eval, (ConvS1Prob, ConvPwProb)):
                             eval_skip.discard(sink[3])       # (the general kernel has no residual operand: keep the fuse launch)
                             sink = None
                         if sink is not None:

@@ -51,6 +51,12 @@ class ConvS1wProb(C.Structure):
         (n, C.c_uint) for n in ('x_bytes', 'w_bytes', 'y_bytes', 'magic_spp', 'magic_hw', 'magic_hh', 'magic_nt', 'magic_tb', 'magic_ta')]
 
 
+class ConvPwProb(C.Structure):
+    _fields_ = [('x', c_fp), ('w', c_fp), ('y', c_fp), ('bias', c_fp), ('stats', c_fp), ('res', c_fp), ('bnb', c_fp)] + [
+        (n, C.c_int) for n in ('P', 'Cin', 'Cout', 'NTC', 'l_ntiles', 'n_mtiles', 'ntiles32', 'blk_begin', 'accumulate', 'relu', 'xr')] + [
+        (n, C.c_uint) for n in ('x_bytes', 'w_bytes', 'y_bytes')] + [('pad_', C.c_int)]
+
+
 class HeadBranch(C.Structure):
     _fields_ = [('x', c_fp), ('dx', c_fp), ('gh', c_fp), ('gw', c_fp), ('w1h', c_fp), ('w1w', c_fp), ('Hs', C.c_int), ('Ws', C.c_int),
                 ('Cs', C.c_int), ('c0', C.c_int), ('sh', C.c_float), ('sw', C.c_float), ('accumulate', C.c_int), ('pad_', C.c_int)]
@@ -158,7 +164,7 @@ class PlanOp(C.Structure):
  OP_BN_BWD_FINALIZE, OP_NCHW_TO_NHWC4, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_BILINEAR_FWD, OP_BILINEAR_BWD, OP_FILL,
  OP_CHANNEL_STATS, OP_FORK, OP_JOIN, OP_DEP, OP_BN_EVAL_BATCHED, OP_COLSUM, OP_CONV_S1, OP_FUSE_FWD_MULTI, OP_TERM_BWD_MULTI,
  OP_BN_FINALIZE_MULTI, OP_BN_BWD_FINALIZE_MULTI, OP_WGRAD_REDUCE_MULTI, OP_WGRAD16, OP_BILINEAR_MULTI_FWD,
- OP_BILINEAR_MULTI_BWD, OP_WGRAD1X1, OP_CONV_S1W, OP_WGRAD_C4, OP_CONV_C4, OP_SCATTER_S2) = range(35)
+ OP_BILINEAR_MULTI_BWD, OP_WGRAD1X1, OP_CONV_S1W, OP_WGRAD_C4, OP_CONV_C4, OP_SCATTER_S2, OP_CONV_PW) = range(36)
 
 FIN_CH = 8          # BPB_FIN_CH of include/bpbreid_hip.h: channels per workgroup of the BatchNorm finalize kernels
 
@@ -204,6 +210,7 @@ def init_device():
         check(lib().bpb_conv_init())
         check(lib().bpb_conv_s1_init())
         check(lib().bpb_conv_s1w_init())
+        check(lib().bpb_conv_pw_init())
         check(lib().bpb_wgrad16_init())
         check(lib().bpb_wgrad_c4_init())
         check(lib().bpb_conv_c4_init())
@@ -258,7 +265,7 @@ def call(name, *args):
 # argument kinds of every entry point: p pointer, i int, l long, f float, d double (stream = last 'p')
 PROTOS = {
     'bpb_conv_init': '', 'bpb_head_init': '',
-    'bpb_conv_igemm': 'ppip', 'bpb_argsort_rows_gpu_workspace': 'iip', 'bpb_argsort_rows_gpu': 'piipplp', 'bpb_conv_s1_init': '', 'bpb_conv_s1': 'ppip', 'bpb_conv_s1w_init': '', 'bpb_conv_s1w': 'ppip', 'bpb_wgrad16_init': '', 'bpb_conv_wgrad16': 'ppip', 'bpb_wgrad_c4_init': '', 'bpb_conv_wgrad_c4': 'ppip', 'bpb_conv_c4_init': '', 'bpb_conv_c4': 'pppppiiiiiiip', 'bpb_scatter_stride2': 'ppiiiiiiip', 'bpb_wgrad1x1_init': '', 'bpb_conv_wgrad1x1': 'ppip', 'bpb_fuse_fwd_multi': 'ppiip', 'bpb_term_bwd_multi': 'ppiiip',
+    'bpb_conv_igemm': 'ppip', 'bpb_argsort_rows_gpu_workspace': 'iip', 'bpb_argsort_rows_gpu': 'piipplp', 'bpb_conv_s1_init': '', 'bpb_conv_s1': 'ppip', 'bpb_conv_s1w_init': '', 'bpb_conv_s1w': 'ppip', 'bpb_conv_pw_init': '', 'bpb_conv_pw': 'ppip', 'bpb_wgrad16_init': '', 'bpb_conv_wgrad16': 'ppip', 'bpb_wgrad_c4_init': '', 'bpb_conv_wgrad_c4': 'ppip', 'bpb_conv_c4_init': '', 'bpb_conv_c4': 'pppppiiiiiiip', 'bpb_scatter_stride2': 'ppiiiiiiip', 'bpb_wgrad1x1_init': '', 'bpb_conv_wgrad1x1': 'ppip', 'bpb_fuse_fwd_multi': 'ppiip', 'bpb_term_bwd_multi': 'ppiiip',
     'bpb_bn_finalize_multi': 'ppiip', 'bpb_bn_bwd_finalize_multi': 'ppiip', 'bpb_wgrad_reduce_multi': 'ppiip', 'bpb_conv_wgrad': 'ppip', 'bpb_wgrad_reduce': 'ppiiiiiip', 'bpb_pack_weights': 'piip',
     'bpb_bn_finalize': 'piidppffppppppp', 'bpb_bn_eval_affine': 'ippppfppp', 'bpb_channel_stats': 'plipip',
     'bpb_fuse_fwd': 'pp', 'bpb_term_bwd': 'piip', 'bpb_bn_bwd_finalize': 'piidppippp',
@@ -294,7 +301,7 @@ EXPORTS = [
     'bpb_head_bwd_params', 'bpb_head_bwd_dx', 'bpb_gemm', 'bpb_gemm_grouped', 'bpb_colsum', 'bpb_bn1d_fwd', 'bpb_bn1d_bwd',
     'bpb_ce_label_smooth', 'bpb_ce_weight_grad', 'bpb_pixel_ce', 'bpb_part_triplet', 'bpb_part_triplet_bwd', 'bpb_scale', 'bpb_adam_step',
     'bpb_fill', 'bpb_plan_run', 'bpb_plan_run2', 'bpb_tape_function', 'bpb_tape_signature', 'bpb_tape_run', 'bpb_add_i64', 'bpb_copy2d', 'bpb_event_create', 'bpb_event_destroy', 'bpb_plan_run_timed', 'bpb_part_distance', 'bpb_part_distance_fill', 'bpb_l2_normalize_rows', 'bpb_eval_rank',
-    'bpb_mask_preprocess', 'bpb_re_ranking', 'bpb_re_ranking_gpu', 'bpb_re_ranking_gpu_workspace', 'bpb_eval_rank_gpu', 'bpb_bn_eval_affine_batched', 'bpb_resize_masks', 'bpb_attention_from_masks', 'bpb_pixel_dots_multi', 'bpb_masked_pool_multi', 'bpb_pool_finalize_multi', 'bpb_argsort_rows_gpu_workspace', 'bpb_argsort_rows_gpu', 'bpb_conv_s1_init', 'bpb_conv_s1', 'bpb_conv_s1w_init', 'bpb_conv_s1w', 'bpb_wgrad16_init', 'bpb_conv_wgrad16', 'bpb_wgrad_c4_init', 'bpb_conv_wgrad_c4', 'bpb_conv_c4_init', 'bpb_conv_c4', 'bpb_scatter_stride2', 'bpb_wgrad1x1_init', 'bpb_conv_wgrad1x1', 'bpb_fuse_fwd_multi', 'bpb_term_bwd_multi', 'bpb_bn_finalize_multi',
+    'bpb_mask_preprocess', 'bpb_re_ranking', 'bpb_re_ranking_gpu', 'bpb_re_ranking_gpu_workspace', 'bpb_eval_rank_gpu', 'bpb_bn_eval_affine_batched', 'bpb_resize_masks', 'bpb_attention_from_masks', 'bpb_pixel_dots_multi', 'bpb_masked_pool_multi', 'bpb_pool_finalize_multi', 'bpb_argsort_rows_gpu_workspace', 'bpb_argsort_rows_gpu', 'bpb_conv_s1_init', 'bpb_conv_s1', 'bpb_conv_s1w_init', 'bpb_conv_s1w', 'bpb_conv_pw_init', 'bpb_conv_pw', 'bpb_wgrad16_init', 'bpb_conv_wgrad16', 'bpb_wgrad_c4_init', 'bpb_conv_wgrad_c4', 'bpb_conv_c4_init', 'bpb_conv_c4', 'bpb_scatter_stride2', 'bpb_wgrad1x1_init', 'bpb_conv_wgrad1x1', 'bpb_fuse_fwd_multi', 'bpb_term_bwd_multi', 'bpb_bn_finalize_multi',
     'bpb_bn_bwd_finalize_multi', 'bpb_wgrad_reduce_multi',
     'bpb_masked_maxpool_fwd', 'bpb_masked_maxpool_bwd_dmask', 'bpb_masked_maxpool_bwd_dx',
     'bpb_weighted_sum', 'bpb_scalar_fanout', 'bpb_lowres_stats_rows', 'bpb_lowres_stats', 'bpb_lowres_upsample_sum', 'bpb_lowres_adjoint', 'bpb_lowres_dx',

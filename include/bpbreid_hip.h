@@ -141,6 +141,32 @@ typedef struct BpbConvS1Prob {
     int tstore;             // 1: epilogue through an LDS transpose, 16-byte stores (plain forward problems of single-tile waves)
 } BpbConvS1Prob;
 
+/* Pointwise (1x1, stride 1) convolution as a plain [P pixels x Cin] . [Cin x Cout] GEMM on NHWC tensors (csrc/conv_pw.hip):
+ * persistent workgroups, the weight slice of a workgroup resident in LDS, autonomous waves that load their A fragments straight
+ * from global memory.  Forward and data gradient of torchreid/models/hrnet.py:104-110,184 and torchreid/models/resnet.py:119-127
+ * (Bottleneck conv1 / conv3 / downsample) where Cin is 64, 128, 192 or 256 and Cout a multiple of 64.  Epilogue fields as in
+ * BpbConvS1Prob. */
+typedef struct BpbConvPwProb {
+    const float* x;         // [P][Cin]
+    const float* w;         // packed [Cin/4][Cout][4] (the 1x1 case of bpb_pack_weights' forward / data-gradient packing)
+    float* y;               // [P][Cout]
+    const float* bias;      // optional [Cout]
+    double* stats;          // optional [n_mtiles][2][Cout]: one (sum, sumsq) row per workgroup group
+    const float* res;       // optional [P][Cout]: y = act(conv + bias + res)
+    const BpbS1BnBwd* bnb;  // optional (device pointer, needs `stats`): `stats` receives the BatchNorm-backward partials instead
+    int P;                  // pixels = N * H * W
+    int Cin, Cout;
+    int NTC;                // output channels per workgroup: 64, 128 or 256 (64 unless Cin == 64)
+    int l_ntiles;           // log2 of the column blocks: Cout = NTC << l_ntiles
+    int n_mtiles;           // workgroups along the pixel axis (wave w of group g walks the 32-pixel tiles 4 g + w, + 4 n_mtiles, ...)
+    int ntiles32;           // ceil(P / 32)
+    int blk_begin;          // first blockIdx of this problem inside a grouped launch
+    int accumulate, relu;   // y += result ; y = max(y, 0)
+    int xr;                 // 1: XCD-aware block map (the column blocks of one pixel group on one XCD)
+    unsigned x_bytes, w_bytes, y_bytes;
+    int pad_;
+} BpbConvPwProb;
+
 /* Data gradient of a STRIDE-2 3x3 pad-1 convolution on the lean kernel family (csrc/conv_s1w.hip): the four input-pixel parity
  * classes are dense stride-1 problems on dy with 1x1 / 1x2 / 2x1 / 2x2 windows whose outputs interleave in dx,
  *   dx[n][2a + ph][2b + pw][:] (+)= sum_{u <= ph, v <= pw} dy[n][a + u][b + v][:] . W[ph + 1 - 2u][pw + 1 - 2v]^T,
@@ -363,6 +389,7 @@ typedef enum BpbOpKind {
     BPB_OP_WGRAD_C4 = 32,          /* p0 device BpbWgradProb[], p1 host copy, i0 nprobs */
     BPB_OP_CONV_C4 = 33,           /* p0 x, p1 w, p2 y, p3 bias, p4 stats, i0 N, i1 Hi, i2 Wi, i3 R, i4 Cout, i5 relu, i6 nblk */
     BPB_OP_SCATTER_S2 = 34,        /* p0 src, p1 dst, i0 N, i1 A, i2 B, i3 H, i4 W, i5 C, i6 accumulate */
+    BPB_OP_CONV_PW = 35,           /* p0 device BpbConvPwProb[], p1 host copy, i0 nprobs */
 } BpbOpKind;
 
 // generic op record; slot meaning per kind is documented next to each case; i[10] = stream slot (0 = the caller's stream, 1..3 = branch streams,
@@ -401,6 +428,9 @@ int bpb_wgrad_reduce_multi(const BpbWgradReduceDesc* d_descs, const BpbWgradRedu
                            hipStream_t stream);
 int bpb_conv_s1_init(void);
 int bpb_conv_s1(const BpbConvS1Prob* d_probs, const BpbConvS1Prob* h_probs, int nprobs, hipStream_t stream);
+/* pointwise convolutions with K <= 256 as persistent GEMM workgroups (csrc/conv_pw.hip), grouped launch of one variant */
+int bpb_conv_pw_init(void);
+int bpb_conv_pw(const BpbConvPwProb* d_probs, const BpbConvPwProb* h_probs, int nprobs, hipStream_t stream);
 /* parity classes of strided 3x3 data gradients (conv backward-input of hrnet.py:240-250 / resnet.py:31-49 stride-2 convolutions) */
 int bpb_conv_s1w_init(void);
 int bpb_conv_s1w(const BpbConvS1wProb* d_probs, const BpbConvS1wProb* h_probs, int nprobs, hipStream_t stream);

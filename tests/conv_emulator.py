@@ -372,6 +372,98 @@ def run_conv_s1(p, x, wpk, y, bias=None, res=None, bn=None):
     return stats
 
 
+def run_conv_pw(p, x, wpk, y, bias=None, res=None, bn=None):
+    """Re-executes bpb_conv_pw_kernel (csrc/conv_pw.hip) at the level of its addressing: the block -> (pixel group, column block)
+    map, the weight slice as the DMA lays it out in LDS (slot (q, n) <- w[(q * Cout + col0 + n)][0..3]), every wave's tile walk
+    (4 g + wave, + 4 n_mtiles, ...), the A fragments as the lanes load them (lane (row, half): x[row][64 c + 8 kg + 4 half ..+3],
+    zeros beyond the tensor), the B fragment slots, the C layout of the 32x32 MFMA in the epilogue offsets and the per-workgroup
+    BatchNorm partial rows.  x [P, Cin], wpk flat packed [Cin/4][Cout][4], y [P, Cout] (in/out).  Returns stats [n_mtiles, 2, Cout].
+    bn = (out | None, src, mean, invstd): the fused BatchNorm-backward epilogue."""
+    P, cin, cout, ntc = p.P, p.Cin, p.Cout, p.NTC
+    n_nt = 1 << p.l_ntiles
+    assert cout == ntc * n_nt and cin % 64 == 0 and ntc % 64 == 0 and p.ntiles32 == -(-P // 32)
+    kc1 = cin == 64
+    assert kc1 or ntc == 64
+    KC = 1 if kc1 else cin // 64
+    npass = ntc // 64 if kc1 else 1
+    xf, yf = x.reshape(-1), y.reshape(-1)
+    stats = np.zeros((p.n_mtiles, 2, cout))
+    nblk = p.n_mtiles * n_nt
+    seen, tiles_done = set(), {}
+    l31 = np.arange(32)
+    for blk in range(nblk):
+        bid = blk
+        if p.xr:
+            q8, r8, f8 = nblk >> 3, nblk & 7, blk & 7
+            bid = f8 * q8 + min(f8, r8) + (blk >> 3)
+        assert 0 <= bid < nblk and bid not in seen, 'the block map is not a bijection'
+        seen.add(bid)
+        ncol, g = bid & (n_nt - 1), bid >> p.l_ntiles
+        # ---- weight slice in LDS
+        wslots = (cin // 4) * ntc
+        assert wslots % 256 == 0
+        lds = np.zeros(wslots * 4)
+        for idx in range(wslots):
+            n, q = idx & (ntc - 1), idx // ntc
+            off = (q * cout + ncol * ntc + n) * 16
+            assert off + 16 <= p.w_bytes
+            lds[idx * 4:idx * 4 + 4] = wpk[off // 4:off // 4 + 4]
+        red = np.zeros((4, ntc, 2))
+        for wave in range(4):
+            t = g * 4 + wave
+            while t < p.ntiles32:
+                tiles_done[(t, ncol)] = tiles_done.get((t, ncol), 0) + 1
+                rows = t * 32 + l31
+                for ps in range(npass):
+                    acc = np.zeros((32, 64))
+                    for c in range(KC):
+                        for kg in range(8):
+                            for half in range(2):
+                                a = np.zeros((32, 4))
+                                for r_ in range(32):
+                                    if rows[r_] < P:
+                                        off = rows[r_] * cin * 4 + half * 16 + c * 256 + kg * 32
+                                        assert off + 16 <= p.x_bytes
+                                        a[r_] = xf[off // 4:off // 4 + 4]
+                                for nt in range(2):
+                                    slot = ((c * 16 + kg * 2 + half) * ntc + ps * 64 + nt * 32 + l31)
+                                    b = lds[slot[:, None] * 4 + np.arange(4)[None, :]]                 # [32 columns][4]
+                                    acc[:, nt * 32:nt * 32 + 32] += a @ b.T
+                    # epilogue: register r of lane (column, half) holds row (r & 3) + 8 * (r >> 2) + 4 * half
+                    for nt in range(2):
+                        for half in range(2):
+                            for r_ in range(16):
+                                row = (r_ & 3) + 8 * (r_ >> 2) + 4 * half
+                                pix = t * 32 + row
+                                if pix >= P:
+                                    continue
+                                for col in range(32):
+                                    co = ncol * ntc + ps * 64 + nt * 32 + col
+                                    off = pix * cout + co
+                                    assert off * 4 + 4 <= p.y_bytes
+                                    v = acc[row, nt * 32 + col] + (bias[co] if bias is not None else 0.0)
+                                    if p.accumulate:
+                                        v += yf[off]
+                                    if res is not None:
+                                        v += res.reshape(-1)[off]
+                                    if p.relu:
+                                        v = max(v, 0.0)
+                                    yf[off] = v
+                                    cl = ps * 64 + nt * 32 + col
+                                    if bn is not None:
+                                        o_, src_, mean_, invstd_ = bn
+                                        gg = v if (o_ is None or o_.reshape(-1)[off] > 0) else 0.0
+                                        red[wave, cl, 0] += gg
+                                        red[wave, cl, 1] += gg * (src_.reshape(-1)[off] - mean_[co]) * invstd_[co]
+                                    else:
+                                        red[wave, cl, 0] += v
+                                        red[wave, cl, 1] += v * v
+                t += p.n_mtiles * 4
+        stats[g, :, ncol * ntc:(ncol + 1) * ntc] = red.sum(0).T
+    assert len(tiles_done) == p.ntiles32 * n_nt and all(v == 1 for v in tiles_done.values()), 'every (tile, column block) exactly once'
+    return stats
+
+
 S1W_WIN = (0, 0, 0, 0, 1, 1, 2, 2, 3)          # csrc/conv_s1w.hip: window position, filter tap, parity class of the nine products
 S1W_TAP = (4, 5, 7, 8, 3, 6, 1, 2, 0)
 S1W_CLS = (0, 1, 2, 3, 1, 3, 2, 3, 3)

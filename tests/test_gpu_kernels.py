@@ -206,7 +206,7 @@ def test_conv_multi_tile_workgroups(case, dma, mode):
 
 @pytest.mark.parametrize('s1', [True, False])
 @pytest.mark.parametrize('case', CONV_CASES)
-def test_conv_forward_backward(case, s1, tile=None, tpb=None, dma=True, ck=None):
+def test_conv_forward_backward(case, s1, tile=None, tpb=None, dma=True, ck=None, pw_min=None, relu=False):
     n, h, w, cin, cout, k, stride, pad = case
     g = torch.Generator().manual_seed(1000 + sum(case))
     x = torch.randn(n, cin, h, w, generator=g)
@@ -220,6 +220,8 @@ def test_conv_forward_backward(case, s1, tile=None, tpb=None, dma=True, ck=None)
     net.force_tpb = tpb
     net.use_dma = dma
     net.force_ck = ck
+    if pw_min is not None:
+        net.pw_min_pixels = pw_min
     cpad = 4 if cin == 3 else cin
     xa = Act(net, n, h, w, cpad)
     xa.needs_grad = cin != 3
@@ -234,10 +236,14 @@ def test_conv_forward_backward(case, s1, tile=None, tpb=None, dma=True, ck=None)
     node = net.conv(xa, wp, stride, pad, bn=(gamma, beta, rm, rv))
     out = net.fuse([(node, 0)], relu=False)
     net.finalize(train_backward=True)
+    if pw_min is not None:
+        assert net.debug_pw and any(m_['label'].startswith('conv_fwd bpb_conv_pw_kernel') for m_ in net.plan_train[2]), 'pointwise kernel not selected'
     lean = stride in (1, 2) and k in (1, 3) and pad == k // 2 and cin % 8 == 0 and cout % 8 == 0
     stem = cin == 3 and cout == 64 and stride == 2 and k in (3, 7) and pad == k // 2
     if stem:                          # csrc/conv_c4.hip with the lean family, the general kernel otherwise
         assert len(net.debug_c4) == (1 if s1 else 0) and len(net.debug_convs) == (0 if s1 else 1), 'kernel selection (stem)'
+    elif pw_min is not None:
+        pass
     elif ck is None and tile is None:   # (a forced tile / chunk that does not fit the 12-piece DMA budget falls back to the general kernel)
         assert isinstance(net.debug_convs[0][0], nv.ConvS1Prob) == (s1 and lean), 'kernel selection'
     net.run(net.plan_train)
@@ -265,6 +271,79 @@ def test_conv_forward_backward(case, s1, tile=None, tpb=None, dma=True, ck=None)
     assert rel_err(gamma.grad, gb.grad) < 1e-4 and rel_err(beta.grad, bb.grad) < 1e-4, 'bn param grads'
     if xa.needs_grad:
         assert rel_err(nchw(xa.grad), xr.grad) < 1e-4, 'dgrad'
+
+
+PW_CASES = [(2, 9, 7, 64, 64), (1, 11, 6, 64, 256), (3, 5, 5, 256, 64), (2, 8, 4, 128, 128), (1, 7, 9, 192, 64), (2, 6, 6, 64, 128), (4, 32, 16, 64, 512),
+            (8, 64, 32, 64, 64), (8, 64, 32, 64, 256), (8, 64, 32, 256, 64), (16, 32, 16, 256, 128), (16, 32, 16, 128, 256)]
+
+
+@pytest.mark.parametrize('case', PW_CASES)
+def test_pointwise_conv_kernel_forward_backward(case):
+    """csrc/conv_pw.hip (stand-alone 1x1 stride-1 convolutions with K <= 256: persistent workgroups, weight slice resident in LDS,
+    autonomous waves) through the plan: forward + BatchNorm partial rows, data gradient, the weight gradient beside it; ragged pixel
+    counts (the last 32-pixel tile reads zeros through the buffer descriptor), one to four column blocks, every K."""
+    n, h, w, cin, cout = case
+    test_conv_forward_backward((n, h, w, cin, cout, 1, 1, 0), True, pw_min=1)
+
+
+@pytest.mark.parametrize('cin,cout', [(64, 256), (256, 64), (128, 128)])
+def test_pointwise_conv_kernel_epilogues(cin, cout):
+    """The epilogue variants of bpb_conv_pw called directly: bias + residual operand + ReLU (the eval plan's folded BatchNorm form),
+    accumulate (data gradients into an existing gradient), BatchNorm-backward partials (BpbS1BnBwd) with and without a ReLU mask --
+    against fp64, bit-identical from run to run."""
+    import conv_emulator as emu
+    P = 2 * 37 * 19                                      # ragged: 1406 pixels = 43 tiles + 30 rows
+    g = torch.Generator().manual_seed(cin + 7 * cout)
+    x = torch.randn(P, cin, generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5
+    bias, res = torch.randn(cout, generator=g), torch.randn(P, cout, generator=g)
+    wpk = torch.from_numpy(emu.pack_fwd(wt.numpy(), cin)).to(DEV)
+    xd, resd, biasd = x.to(DEV), res.to(DEV), bias.to(DEV)
+    net = Net(DEV)
+    net.pw_min_pixels = 1
+
+    def launch(y, **kw):
+        p = net.pw_problem(xd, P, wpk, y, cin, cout, bias=kw.get('bias'), accumulate=kw.get('accumulate', 0), relu=kw.get('relu', 0))
+        assert p is not None
+        if kw.get('res') is not None:
+            p.res = kw['res'].data_ptr()
+        part = None
+        if kw.get('bnb') is not None:
+            o_, src_, mean_, invstd_ = kw['bnb']
+            bb = nv.S1BnBwd()
+            bb.out = o_.data_ptr() if o_ is not None else None
+            bb.src, bb.mean, bb.invstd = src_.data_ptr(), mean_.data_ptr(), invstd_.data_ptr()
+            p.bnb = net._dev_struct(bb).data_ptr()
+            part = torch.zeros(p.n_mtiles * 2 * cout, device=DEV, dtype=torch.float64)
+            p.stats = part.data_ptr()
+        host = (nv.ConvPwProb * 1)(p)
+        nv.call('bpb_conv_pw', net._dev_struct(host).data_ptr(), host, 1, nv.stream())
+        torch.cuda.synchronize()
+        return part, p
+    ref = x.double() @ wt.reshape(cout, cin).double().t()
+    y = torch.full((P, cout), float('nan'), device=DEV)
+    launch(y, bias=biasd, res=resd, relu=1)
+    assert rel_err(y, torch.relu(ref + bias.double() + res.double())) < 2e-5
+    y0 = torch.randn(P, cout, generator=g)
+    y = y0.to(DEV)
+    launch(y, accumulate=1)
+    assert rel_err(y, ref + y0.double()) < 2e-5
+    # BatchNorm-backward partials: G = v where O > 0, sums of G and G * xhat
+    o_ = torch.randn(P, cout, generator=g)
+    src = torch.randn(P, cout, generator=g)
+    mean, invstd = torch.randn(cout, generator=g), torch.rand(cout, generator=g) + 0.5
+    for with_out in (True, False):
+        y = torch.full((P, cout), float('nan'), device=DEV)
+        part, p = launch(y, bnb=(o_.to(DEV) if with_out else None, src.to(DEV), mean.to(DEV), invstd.to(DEV)))
+        y2 = torch.full((P, cout), float('nan'), device=DEV)
+        part2, _ = launch(y2, bnb=(o_.to(DEV) if with_out else None, src.to(DEV), mean.to(DEV), invstd.to(DEV)))
+        assert torch.equal(y, y2) and torch.equal(part, part2), 'run-to-run determinism'
+        assert rel_err(y, ref) < 2e-5
+        gmask = (o_ > 0).double() if with_out else torch.ones(P, cout, dtype=torch.float64)
+        G = ref * gmask
+        rows = part.view(p.n_mtiles, 2, cout).sum(0).cpu()
+        assert rel_err(rows[0], G.sum(0)) < 2e-5
+        assert rel_err(rows[1], (G * (src.double() - mean.double()) * invstd.double()).sum(0)) < 2e-5
 
 
 @pytest.mark.parametrize('ratio', ['2', '8'])

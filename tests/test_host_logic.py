@@ -213,8 +213,9 @@ def test_standalone_1x1_convolutions_take_128_pixel_tiles_where_every_cu_still_g
     """Plan-time tile rule of 1x1 launches that stand alone (ResNet-50 layers 2-4, profiles/r04_s1_sweep_1x1.txt): 128 pixels x 64
     channels with 32-channel chunks where the convolution narrows (K >= 256), 128 x 128 where it widens by 4; the round-3 tile at
     small batches (too few workgroups), inside fork regions (one kernel variant per grouped launch) and with the switch off."""
-    def tile(n, h, w, cin, cout, region=False):
+    def tile(n, h, w, cin, cout, region=False, pw=False):
         net = Net(torch.device('cpu'))
+        net.use_pw = pw          # (the K <= 256 shapes go to bpb_conv_pw by default: this test is about bpb_conv_s1's tile rule)
         if region:
             net.fork(2)
             net.set_slot(0)
@@ -231,6 +232,8 @@ def test_standalone_1x1_convolutions_take_128_pixel_tiles_where_every_cu_still_g
             net.set_slot(0)
             net.join(2)
         net.finalize(train_backward=False)
+        if pw:
+            return len(net.debug_pw), len(net.debug_convs)
         p = net.debug_convs[0][0]
         return p.mt_r, p.lwn, p.nt, p.CK
 
@@ -241,6 +244,10 @@ def test_standalone_1x1_convolutions_take_128_pixel_tiles_where_every_cu_still_g
     assert tile(64, 16, 8, 512, 2048) == (2, 1, 2, 32)
     assert tile(64, 64, 32, 64, 256) == (1, 1, 2, 32)         # layer 1: K = 64, the round-3 tile
     assert tile(64, 64, 32, 256, 64) == (1, 0, 2, 32)
+    # with the pointwise kernel on (the default): layer 1's shapes leave bpb_conv_s1, K > 256 / many column blocks / fork regions stay
+    assert tile(64, 64, 32, 64, 256, pw=True) == (1, 0) and tile(64, 64, 32, 256, 64, pw=True) == (1, 0)
+    assert tile(64, 16, 8, 1024, 256, pw=True) == (0, 1) and tile(64, 16, 8, 256, 1024, pw=True) == (0, 1)
+    assert tile(64, 64, 32, 64, 64, region=True, pw=True) == (0, 2) and tile(4, 16, 8, 64, 64, pw=True) == (0, 1)
     assert tile(8, 16, 8, 1024, 256) == (1, 1, 2, 32)         # batch 8: 32 workgroups of the large tile -> not used
     assert tile(64, 16, 8, 1024, 256, region=True) == (1, 1, 2, 32)
     monkeypatch.setenv('BPB_S1_1X1_TILES', '0')
@@ -332,6 +339,66 @@ def test_conv_descriptors_forward_dgrad_wgrad(case):
         assert not (k == 1 and cin >= 64 and cout >= 64 and node.y.H >= 2 and node.y.W >= 2)
     ref_dw = wr.grad.permute(2, 3, 1, 0).reshape(k * k, cin, cout).numpy()
     assert np.allclose(dw[:, :cin], ref_dw, atol=1e-8), 'wgrad geometry'
+
+
+@pytest.mark.parametrize('cin,cout,n,h,w', [(64, 64, 2, 9, 7), (64, 256, 1, 11, 6), (256, 64, 3, 5, 5), (128, 128, 2, 8, 4), (192, 64, 1, 7, 9), (64, 128, 2, 6, 6)])
+def test_pointwise_convolution_descriptors_forward_and_dgrad(cin, cout, n, h, w):
+    """Stand-alone 1x1 stride-1 convolutions with K <= 256 take bpb_conv_pw (csrc/conv_pw.hip): persistent workgroups, weight slice
+    resident, autonomous waves.  The descriptor is emulated at the level of the kernel's addressing (tests/conv_emulator.py:
+    run_conv_pw) for forward (BatchNorm partial rows included) and data gradient; ragged pixel counts, one and several column blocks."""
+    g = torch.Generator().manual_seed(cin * 1000 + cout)
+    wt = torch.randn(cout, cin, 1, 1, generator=g, dtype=torch.float64)
+    wt_param = wt.float().clone()
+    wt_param.grad = torch.zeros_like(wt_param)
+    xin = torch.randn(n, cin, h, w, generator=g, dtype=torch.float64)
+    net = Net(torch.device('cpu'))
+    net.pw_min_pixels = 1
+    x = Act(net, n, h, w, cin)
+    x.needs_grad = True
+    gam = torch.ones(cout)
+    gam.grad = torch.zeros(cout)
+    bet = torch.zeros(cout)
+    bet.grad = torch.zeros(cout)
+    node = net.conv(x, wt_param, 1, 0, bn=(gam, bet, torch.zeros(cout), torch.ones(cout)))
+    net.fuse([(node, 0)], relu=True)
+    net.finalize(train_backward=True)
+    if cin == 192:       # the data gradient 64 -> 192 would need three column blocks (not a power of two): it stays on bpb_conv_s1
+        assert len(net.debug_pw) == 1 and len(net.debug_convs) == 1 and isinstance(net.debug_convs[0][0], nv.ConvS1Prob)
+        fp, dp = net.debug_pw[0][0], None
+    else:
+        assert len(net.debug_pw) == 2 and not net.debug_convs, 'forward and data gradient on the pointwise kernel'
+        fp, dp = net.debug_pw[0][0], net.debug_pw[1][0]
+    assert any(r.kind == nv.OP_CONV_PW for r in net.fwd_train) and any(r.kind == nv.OP_CONV_PW for r in net.fwd_eval)
+    assert (fp.P, fp.Cin, fp.Cout) == (n * h * w, cin, cout) and (dp is None or (dp.Cin, dp.Cout) == (cout, cin))
+    x2 = xin.permute(0, 2, 3, 1).reshape(-1, cin).numpy().copy()
+    y = np.zeros((n * h * w, cout))
+    stats = emu.run_conv_pw(fp, x2, emu.pack_fwd(wt.numpy(), cin), y)
+    ref = F.conv2d(xin, wt).permute(0, 2, 3, 1).reshape(-1, cout).numpy()
+    assert np.allclose(y, ref, atol=1e-9), 'forward addressing'
+    assert np.allclose(stats[:, 0].sum(0), ref.sum(0), atol=1e-8) and np.allclose(stats[:, 1].sum(0), (ref ** 2).sum(0), atol=1e-7)
+    assert fp.stats and stats.shape[0] == fp.n_mtiles
+    # the BatchNorm finalize record reads exactly the rows the kernel writes
+    fin = [r for r in net.fwd_train if r.kind == nv.OP_BN_FINALIZE_MULTI][0].desc
+    assert fin.nparts == fp.n_mtiles and fin.partials == fp.stats
+    gy = torch.randn(n * h * w, cout, generator=g, dtype=torch.float64).numpy()
+    gx = np.zeros((n * h * w, cin))
+    if dp is None:
+        return
+    emu.run_conv_pw(dp, gy, emu.pack_dgrad(wt.numpy(), cin), gx)
+    assert np.allclose(gx, gy @ wt.reshape(cout, cin).numpy(), atol=1e-9), 'data-gradient addressing'
+    # residual operand + ReLU + bias (the eval plan's epilogue), accumulate mode
+    ep = nv.ConvPwProb.from_buffer_copy(fp)
+    ep.relu, ep.stats = 1, None
+    res = np.random.default_rng(0).standard_normal((n * h * w, cout))
+    bias = np.random.default_rng(1).standard_normal(cout)
+    y2 = np.zeros_like(y)
+    emu.run_conv_pw(ep, x2, emu.pack_fwd(wt.numpy(), cin), y2, bias=bias, res=res)
+    assert np.allclose(y2, np.maximum(ref + bias + res, 0), atol=1e-9)
+    ap = nv.ConvPwProb.from_buffer_copy(dp)
+    ap.accumulate = 1
+    gx2 = gx.copy()
+    emu.run_conv_pw(ap, gy, emu.pack_dgrad(wt.numpy(), cin), gx2)
+    assert np.allclose(gx2, 2 * gx, atol=1e-9)
 
 
 @pytest.mark.parametrize('case', [(3, 10, 6, 16, 24, 3), (2, 9, 7, 32, 40, 1), (5, 4, 4, 8, 8, 3)])

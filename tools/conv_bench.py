@@ -14,6 +14,9 @@ SHAPES = [  # H, W, Cin, Cout, k, stride
     (64, 32, 64, 64, 3, 1), (64, 32, 64, 256, 1, 1), (64, 32, 256, 64, 1, 1), (128, 64, 64, 64, 3, 2), (256, 128, 3, 64, 3, 2),
     (64, 32, 32, 64, 3, 2), (32, 16, 64, 32, 1, 1), (8, 4, 256, 1024, 1, 1), (16, 8, 128, 512, 1, 1),
 ]
+if os.environ.get('ONLY') == '1x1':      # the stand-alone pointwise shapes (layer 1 of both backbones, ResNet-50 layer 2): BPB_CONV_PW=0/1
+    SHAPES = [(64, 32, 64, 64, 1, 1), (64, 32, 64, 256, 1, 1), (64, 32, 256, 64, 1, 1), (64, 32, 256, 128, 1, 1), (32, 16, 128, 512, 1, 1),
+              (32, 16, 256, 128, 1, 1), (32, 16, 128, 128, 1, 1)]
 print('%-28s %9s %9s %9s   (TFLOP/s; us)' % ('shape', 'fwd', 'dgrad', 'wgrad'))
 for (h, w, cin, cout, k, st) in SHAPES:
     net = Net(dev)
@@ -33,9 +36,9 @@ for (h, w, cin, cout, k, st) in SHAPES:
     torch.cuda.synchronize()
     acc = {}
     for rep in range(10):
-        for plan in (net.plan_train, net.plan_bwd):
+        for plan in (net.plan_train, net.plan_bwd, net.plan_eval):
             for meta, ms in net.run_timed(plan):
-                key = meta['label'].split(' ')[0]
+                key = meta['label'].split(' ')[0] + ('_eval' if plan is net.plan_eval else '')
                 a = acc.setdefault(key, [0.0, 0.0])
                 a[0] += ms; a[1] += meta['flops'] if rep == 0 else 0
     def tf(key):
@@ -43,4 +46,5 @@ for (h, w, cin, cout, k, st) in SHAPES:
         ms = acc[key][0] / 10
         return '%5.1f/%4.0f' % (acc[key][1] / (ms * 1e-3) / 1e12, ms * 1e3)
     extra = ' '.join('%s=%.0fus' % (k2, acc[k2][0] / 10 * 1e3) for k2 in ('fuse_fwd', 'bn_finalize', 'bn_bwd_reduce', 'bn_bwd_apply', 'wgrad_reduce', 'bn_bwd_finalize') if k2 in acc)
+    extra += ' eval_fwd=' + tf('conv_fwd_eval').strip()
     print('%-28s %9s %9s %9s   %s' % ('%dx%d %d->%d k%d s%d' % (h, w, cin, cout, k, st), tf('conv_fwd'), tf('conv_dgrad'), tf('conv_wgrad'), extra))
