@@ -497,6 +497,19 @@ def main():
         elapsed, host_enqueue, host_enqueue_min = float(t[0]), float(t[1]), -float(t[2])    # the slowest rank sets the step; the
                                                                                             # busiest / idlest host loops are reported
     final_loss = float(loss.detach())
+    # host cost of a step: a SHORT burst behind an empty queue.  (The timed loop above enqueues 20 steps = ~25 000 launches in a row:
+    # once the hardware queue is full the enqueue calls block until the GPU drains it, and the loop's wall time per step converges to
+    # the GPU's -- 21 of 30 ms -- whatever the host really spends.  Four steps fit the queue: this is the CPU work per step.)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(4):
+        step()
+    host_burst = (time.perf_counter() - t1) / 4
+    torch.cuda.synchronize()
+    if multi:
+        hb = torch.tensor([host_burst], device=dev, dtype=torch.float64)
+        dist.all_reduce(hb, op=dist.ReduceOp.MAX)
+        host_burst = float(hb[0])
     exchange = None
     if multi:
         try:
@@ -540,8 +553,9 @@ def main():
                                'visibility masks, fwd+loss+bwd+all-reduce+Adam (BASELINE configs[2]/[3])'
                                % (args.backbone, args.parts, args.height, args.width, args.batch, args.batch * world),
                    'parallelism': 'dp%d' % world, 'global_batch': args.batch * world, 'final_loss': final_loss,
-                   'host_enqueue_ms_per_step': 1e3 * host_enqueue / args.steps, 'launch_mode': mode,
-                   'host_enqueue_ms_per_step_min_over_ranks': 1e3 * (host_enqueue_min if multi else host_enqueue) / args.steps,
+                   'host_enqueue_ms_per_step': 1e3 * host_burst, 'launch_mode': mode,
+                   'host_loop_ms_per_step_with_queue_backpressure': 1e3 * host_enqueue / args.steps,
+                   'host_loop_ms_per_step_min_over_ranks': 1e3 * (host_enqueue_min if multi else host_enqueue) / args.steps,
                    'host_fraction_of_step_before_choosing_the_launch_mode': host_bound, 'launch_mode_probe': choice,
                    'taped_step': eng.fused_reason is None, 'taped_step_not_used_because': eng.fused_reason,
                    'host_cores_per_rank': len(pinned) if pinned else host_cores(),

@@ -60,6 +60,35 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_pw_kernel(const BpbConvPwProb
         if (do_stats)
             for (int i = threadIdx.x; i < 4 * NTC * 2; i += 256) red[i] = 0.0;
     }
+    // per-channel epilogue constants of this workgroup's columns -> LDS: [bias | mean | invstd][NTC].  (Read with global_load inside
+    // the item loop they made hipcc wait vmcnt(0) at the first MFMA of every pass -- behind the previous pass's 32 stores; the ISA
+    // shows counted waits once no global_load is left between the MFMA phases.)
+    float* cvals = (float*)(red + 4 * NTC * 2);
+    const bool bn_bwd = do_stats && P.bnb != nullptr;
+    const float* bn_out = nullptr;
+    const float* bn_src = nullptr;
+    {
+        auto uniform_ptr = [](const void* p_) {
+            const unsigned long long u = (unsigned long long)p_;
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+            return (const float*)(((unsigned long long)hi << 32) | lo);
+        };
+        bpb_gcf mean_p = nullptr, invstd_p = nullptr;
+        if (bn_bwd) {
+            const BpbS1BnBwd* bp = P.bnb;
+            bn_out = uniform_ptr(bp->out);
+            bn_src = uniform_ptr(bp->src);
+            mean_p = (bpb_gcf)uniform_ptr(bp->mean);
+            invstd_p = (bpb_gcf)uniform_ptr(bp->invstd);
+        }
+        const bpb_gcf gbias = (bpb_gcf)P.bias;
+        if ((int)threadIdx.x < NTC) {
+            const int co = ncol * NTC + (int)threadIdx.x;
+            cvals[threadIdx.x] = gbias ? gbias[co] : 0.f;
+            cvals[NTC + threadIdx.x] = bn_bwd ? mean_p[co] : 0.f;
+            cvals[2 * NTC + threadIdx.x] = bn_bwd ? invstd_p[co] : 0.f;
+        }
+    }
 
     // ---- this wave's tiles: t = g * 4 + wave, + n_mtiles * 4, ...
     const int ntiles = P.ntiles32;
@@ -96,25 +125,7 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_pw_kernel(const BpbConvPwProb
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)P.y, 0, (int)P.y_bytes, 0x00020000);
     const bool accum = P.accumulate != 0 || P.res != nullptr, relu = P.relu != 0;
     const __amdgpu_buffer_rsrc_t rold = P.res ? __builtin_amdgcn_make_buffer_rsrc((void*)P.res, 0, (int)P.y_bytes, 0x00020000) : ry;
-    const bpb_gcf gbias = (bpb_gcf)P.bias;
     const int pstride = Cout * 4;
-    const bool bn_bwd = do_stats && P.bnb != nullptr;
-    const float* bn_out = nullptr;
-    const float* bn_src = nullptr;
-    bpb_gcf mean_p = nullptr;        // (global address space: a FLAT load inside the item loop makes the compiler wait vmcnt(0) and
-    bpb_gcf invstd_p = nullptr;      //  lgkmcnt(0) at every later use of any memory result -- pending flat operations are unordered)
-    if (bn_bwd) {
-        auto uniform_ptr = [](const void* p_) {
-            const unsigned long long u = (unsigned long long)p_;
-            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-            return (const float*)(((unsigned long long)hi << 32) | lo);
-        };
-        const BpbS1BnBwd* bp = P.bnb;
-        bn_out = uniform_ptr(bp->out);
-        bn_src = uniform_ptr(bp->src);
-        mean_p = (bpb_gcf)uniform_ptr(bp->mean);
-        invstd_p = (bpb_gcf)uniform_ptr(bp->invstd);
-    }
     const __amdgpu_buffer_rsrc_t rbs = __builtin_amdgcn_make_buffer_rsrc((void*)(bn_src ? bn_src : P.y), 0, (int)P.y_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rbo = __builtin_amdgcn_make_buffer_rsrc((void*)(bn_out ? bn_out : P.y), 0, (int)P.y_bytes, 0x00020000);
 
@@ -186,8 +197,8 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_pw_kernel(const BpbConvPwProb
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const int co = cbase + nt * 32;
-                const float bias_v = gbias ? gbias[co] : 0.f;
+                const int cl = pass * 64 + nt * 32 + l31;
+                const float bias_v = cvals[cl];
                 float old[16];
                 if (accum) {
 #pragma unroll
@@ -197,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_pw_kernel(const BpbConvPwProb
                 double ssum = 0.0, ssq = 0.0;
                 if (bn_bwd) {
                     // data gradient + BatchNorm-backward partials (sum G, sum G * xhat), G = v where O > 0 (bpb_conv_s1, BpbS1BnBwd)
-                    const float mu = mean_p[co], is = invstd_p[co];
+                    const float mu = cvals[NTC + cl], is = cvals[2 * NTC + cl];
                     float bs[16], bo[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
@@ -279,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_pw_kernel(const BpbConvPwProb
 }
 
 // ------------------------------------ C ABI ------------------------------------------
-static int conv_pw_lds_bytes(const BpbConvPwProb& p) { return p.Cin * p.NTC * 4 + 4 * p.NTC * 16; }
+static int conv_pw_lds_bytes(const BpbConvPwProb& p) { return p.Cin * p.NTC * 4 + 4 * p.NTC * 16 + 3 * p.NTC * 4; }
 
 extern "C" {
 

@@ -47,6 +47,8 @@ TUNE = {
     'conv_c4_blocks': 512,       # stem forward: workgroups (each walks a contiguous range of 8 x 16-pixel tiles; two per CU)
     'wgrad_c4_blocks': 512,      # stem weight gradient: workgroups (= split-K slabs of T x 4 x Cout floats)
     'concat_blocks': 2048,       # head concatenation: 8 workgroups per CU
+    'pw_per_cu': 2,              # bpb_conv_pw: persistent workgroups per CU (~195 VGPRs: two = eight waves)
+    'pw_ntc_max': 256,           # bpb_conv_pw with K = 64: widest column block of a workgroup (its weight slice: 64 x NTC x 4 bytes of LDS)
 }
 for _kv in filter(None, os.environ.get('BPB_TUNE', '').split(',')):      # measurement hook: BPB_TUNE=wgrad16_blocks=384,wgrad16_tpb=8
     _k, _v = _kv.split('=')
@@ -491,14 +493,14 @@ class Net:
         ntc = 64
         if cin == 64:
             for c_ in (256, 128):
-                if cout % c_ == 0:
+                if cout % c_ == 0 and c_ <= TUNE['pw_ntc_max']:
                     ntc = c_
                     break
         n_nt = cout // ntc
         if n_nt & (n_nt - 1) or n_nt > 4:
             return None
-        lds = cin * ntc * 4 + 4 * ntc * 16
-        per_cu = max(1, min(2, (160 * 1024) // lds))          # ~195 VGPRs: two workgroups (eight waves) per CU
+        lds = cin * ntc * 4 + 4 * ntc * 16 + 3 * ntc * 4
+        per_cu = max(1, min(TUNE['pw_per_cu'], (160 * 1024) // lds))
         tiles = _cdiv(npix, 32)
         p = ConvPwProb()
         p.x, p.w, p.y = x_buf.data_ptr(), w_packed.data_ptr(), y_buf.data_ptr()

@@ -220,6 +220,7 @@ def test_conv_forward_backward(case, s1, tile=None, tpb=None, dma=True, ck=None,
     net.force_tpb = tpb
     net.use_dma = dma
     net.force_ck = ck
+    net.use_pw = pw_min is not None       # (this test is about bpb_conv_s1 / bpb_conv_igemm unless the pointwise kernel is asked for)
     if pw_min is not None:
         net.pw_min_pixels = pw_min
     cpad = 4 if cin == 3 else cin
