@@ -54,7 +54,7 @@ def parse():
                          'are probed for 5 steps and the faster one runs the timed region (N > 1: the graph is only tried when the '
                          'eager host loop needs more than 85 %% of the step)')
     ap.add_argument('--graph-side-batch', type=int, default=None, help='captured step: weight-gradient launches per fork onto the side '
-                    'stream (0: the whole backward plan on one stream; default: BPB_GRAPH_SIDE_BATCH, else 0)')
+                    'stream (0: the whole backward plan on one stream; default: graph.TUNE[graph_side_batch] = 0)')
     ap.add_argument('--dist-backend', default='nccl', help="'nccl' (= RCCL over xGMI; the default) or 'gloo' (functional check of the "
                     "multi-process path when the ranks have to share one GPU)")
     ap.add_argument('--dump-plan-timing', default='', help='write the per-record isolated timings of the forward and backward '
@@ -112,7 +112,8 @@ def cpu_baseline_subprocess(args):
     if args.cpu_batch:
         legs['train_step'] = _cpu_child(args, 'train', 240, ['--cpu-batch', str(args.cpu_batch)])
     else:
-        legs['train_step'] = _cpu_child(args, 'train', 150, ['--cpu-batch', str(args.batch), '--cpu-steps', '1,2'])
+        # >= 3 warm-up + >= 5 timed steps (6.5-8.3 s per batch-64 step on 16 cores: ~60 s of CPU work)
+        legs['train_step'] = _cpu_child(args, 'train', 300, ['--cpu-batch', str(args.batch), '--cpu-steps', '3,5'])
         if legs['train_step'].get('value') is None:
             note = legs['train_step'].get('sample')
             legs['train_step'] = _cpu_child(args, 'train', 150, ['--cpu-batch', '16'])

@@ -89,6 +89,9 @@ def _emit_parallel_chains(net, chains, xs):
     return outs
 
 
+EXCHANGE_PATHS = True      # one merge chain per exchange PATH (round 3: -1.2 ms per step against one chain per target); tools flip it
+
+
 class MultiResModule(nn.Module):
     """HighResolutionModule (hrnet.py:140-279)."""
 
@@ -147,7 +150,7 @@ class MultiResModule(nn.Module):
                     t = net.fuse([(c, 0)], relu=True)
             return (c, 0)
 
-        if os.environ.get('BPB_EXCHANGE_PATHS', '1') != '0' and nb * (nb - 1) <= 16:
+        if EXCHANGE_PATHS and nb * (nb - 1) <= 16:
             # Round 3: every PATH j -> i is its own chain of a first region (nb * (nb - 1) chains), the nb final sums form a
             # second one.  Recorded per target, the three down-paths into the deepest branch (3 + 2 + 1 strided convolutions)
             # were six convolution rounds of the lock-step merge; per path, step k of every path shares a round: three rounds, each

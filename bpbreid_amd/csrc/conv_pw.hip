@@ -13,7 +13,8 @@
 //     against the MFMAs of the previous 64-channel chunk -- no LDS staging of x, NO barrier after the weight load;
 //   * BatchNorm partials accumulate per wave over all of its tiles (LDS scratch) and leave as ONE row per workgroup.
 // K = 64 (Cin == 64): the A registers of a tile serve every 64-channel pass over the workgroup's NTC <= 256 output channels (x is
-// read exactly once); K = 128 / 192 / 256: NTC = 64, the accumulators run over the chunks (two-level sums like bpb_conv_s1).
+// read exactly once); K = 128 / 192 / 256: NTC = 64, the accumulators run over the chunks (two-level sums over 32-channel sub-sums
+// like bpb_conv_s1's 32-channel chunks).
 // Epilogue = that of bpb_conv_s1 (bias, ReLU, residual operand, accumulate, BatchNorm statistics in fp64, BatchNorm-backward
 // partials of the data-gradient launches).
 #include "bpb_common.h"
@@ -158,6 +159,25 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_pw_kernel(const BpbConvPwProb
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) cacc[nt] = MFMA32(cur[kg][i], fb[kg & 1][nt][i], cacc[nt]);
                 __builtin_amdgcn_sched_barrier(0);
+                if (kg == 3 || kg == 7) {
+                    // two-level summation in 32-channel sub-sums, the granularity of bpb_conv_s1's 32-channel chunks (a single fp32
+                    // chain over 64 products measurably raised the gradient noise of the most chaotic golden fixture)
+                    if (kg == 3 && (KC1 || c == 0)) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[nt] = cacc[nt];
+                    } else {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[nt][r] += cacc[nt][r];
+                    }
+                    if (kg == 3) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) cacc[nt][r] = 0.f;
+                    }
+                }
                 if (kg == 0 && pass == 0 && have_next) {
                     // The next item's loads go out BEHIND the first MFMA group: hipcc (ROCm 7.2) waits vmcnt(0) at the first MFMA of
                     // a loop body whose back edge carries stores (measured in the ISA, whatever the operands), so a prefetch issued in
@@ -165,15 +185,6 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_pw_kernel(const BpbConvPwProb
                     PW_LOAD(nxt, rn, cn);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            }
-            if (KC1 || c == 0) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = cacc[nt];
-            } else {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[nt][r] += cacc[nt][r];
             }
             if (pass + 1 == npass) {     // the last MFMA of the item has been issued: the next item's operands take over
                 if (have_next) {

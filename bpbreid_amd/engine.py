@@ -171,7 +171,9 @@ class ImagePartBasedEngine:
 
         `side_batch`: the two-stream schedule of the captured backward plan -- 0 keeps the whole plan on one stream, B >= 1 puts
         the weight gradients on the side stream with one fork per B of them (graph.Net.side_batch; hipGraph capture follows the
-        fork / join events, every cross-stream edge costs host and device time at replay).  Default: BPB_GRAPH_SIDE_BATCH, else 0.
+        fork / join events, every cross-stream edge costs host and device time at replay).  Default: graph.TUNE['graph_side_batch'] = 0
+        (measured: 31.8 ms on one stream, 31.3-31.6 with 8-32 launches per fork, a memory fault at 1 on HRNet-W32 -- the eager taped
+        step with its two streams runs 30.0 and is what bench.py picks).
         `agree(ok) -> bool`: data-parallel jobs pass a collective AND over the ranks; it is called once after the warm-up steps
         (which contain the gradient all-reduces, so a rank that failed there cannot be waited for: the job is aborted on every
         rank) -- see capture_step_agreed.
@@ -198,7 +200,8 @@ class ImagePartBasedEngine:
         if fused:
             self.optimizer._state()
         if side_batch is None:
-            side_batch = int(os.environ.get('BPB_GRAPH_SIDE_BATCH', '0'))
+            from .graph import TUNE
+            side_batch = TUNE['graph_side_batch']
         net = self.model._plan(imgs.shape[0], imgs.shape[2], imgs.shape[3], imgs.device).net if hasattr(self.model, '_plan') else None
         old_batch = net.side_batch if net is not None else None
         if net is not None:
@@ -398,14 +401,31 @@ class ImagePartBasedEngine:
         from .distributed import all_gather_cat
         return all_gather_cat(torch.as_tensor(list(labels), dtype=torch.int64, device=dev), 0, self.process_group).tolist()
 
+    def individual_parts_ranking(self, body_parts_distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50, eval_metric='default'):
+        """CMC / mAP of every embedding of the test set ON ITS OWN: row p of the [P, Q, G] per-part matrix ranked like the combined
+        matrix (part_based_engine.py:308-339, display_individual_parts_ranking_performances -- the table the reference prints after
+        every evaluation).  A matrix in HBM (what `evaluate(..., return_body_parts_distmat='device')` hands out) is ranked on the GPU,
+        one bpb_eval_rank_gpu pass per part; a host matrix goes through the host routine.  Returns
+        [(title, mAP, rank-1, rank-5, rank-10)] with the reference's row titles ('globl' / 'foreg' for the holistic embeddings in
+        front, then 'p 0', 'p 1', ...)."""
+        titles = [e_ for e_ in ('globl', 'foreg') if e_ in self.test_embeddings or 'bn_' + e_ in self.test_embeddings]
+        rows = []
+        for p in range(body_parts_distmat.shape[0]):
+            res = evaluate_rank(body_parts_distmat[p], q_pids, g_pids, q_camids, g_camids, max_rank=max_rank, eval_metric=eval_metric)
+            cmc = res['cmc']
+            pick = lambda r_: float(cmc[r_]) if len(cmc) > r_ else float('nan')
+            rows.append((titles[p] if p < len(titles) else 'p %d' % (p - len(titles)), float(res['mAP']), pick(0), pick(4), pick(9)))
+        return rows
+
     @torch.no_grad()
     def evaluate(self, qf, gf, q_vis, g_vis, q_pids, g_pids, q_camids, g_camids, dist_metric='euclidean',
                  normalize_feature=True, max_rank=50, rerank=False, return_body_parts_distmat=False, gallery_sharded=False):
         """-> (cmc, mAP, distmat [Q,G] on the host, body_parts_distmat [P,Q,G] on the host or None)  (part_based_engine.py:168-240).
 
         Distance, (re-ranking) and CMC / mAP run on the GPU; the Q x G matrix goes to the host only as the returned value.  The
-        per-part matrix (1.47 GB at Q = 2048, G = 20 000, P = 9: the reference only reads it for its plots and the visual
-        ranking) is produced and copied on request only (`return_body_parts_distmat=True`).
+        per-part matrix (1.47 GB at Q = 2048, G = 20 000, P = 9: the reference only reads it for its per-part ranking table, its
+        plots and the visual ranking) is produced on request only: `return_body_parts_distmat=True` copies it to the host,
+        `='device'` leaves it in HBM (the form `individual_parts_ranking` ranks on the GPU).
         `gallery_sharded=True` on a distributed engine: `gf`, `g_vis`, `g_pids`, `g_camids` are THIS rank's rows
         (`feature_extraction(..., shard=True)`); every rank computes its [Q, G_r] block, the fill value is agreed with one scalar
         all-reduce, the blocks and the labels are all-gathered along the gallery axis and every rank ranks the full matrix
@@ -427,7 +447,9 @@ class ImagePartBasedEngine:
                 g_vis = all_gather_cat(g_vis.to(torch.float32), 0, self.process_group).to(g_vis.dtype) if g_vis is not None else None
         else:
             d_qg, parts_dev = bp(qf, gf, q_vis, g_vis, return_body_parts_distmat)
-        body_parts_distmat = parts_dev.cpu() if (return_body_parts_distmat and parts_dev is not None) else None
+        body_parts_distmat = None
+        if return_body_parts_distmat and parts_dev is not None:
+            body_parts_distmat = parts_dev if return_body_parts_distmat == 'device' else parts_dev.cpu()
         ranked_dev = d_qg
         if rerank:                                                   # part_based_engine.py:218-226, utils/rerank.py:30
             ranked_dev = re_ranking(d_qg, bp(qf, qf, q_vis, q_vis)[0], bp(gf, gf, g_vis, g_vis)[0])

@@ -48,7 +48,12 @@ TUNE = {
     'wgrad_c4_blocks': 512,      # stem weight gradient: workgroups (= split-K slabs of T x 4 x Cout floats)
     'concat_blocks': 2048,       # head concatenation: 8 workgroups per CU
     'pw_per_cu': 2,              # bpb_conv_pw: persistent workgroups per CU (~195 VGPRs: two = eight waves)
-    'pw_ntc_max': 256,           # bpb_conv_pw with K = 64: widest column block of a workgroup (its weight slice: 64 x NTC x 4 bytes of LDS)
+    'pw_ntc_max': 128,           # bpb_conv_pw with K = 64: widest column block of a workgroup (128: 41 KB of LDS, two workgroups per CU;
+                                 # 256 = 83 KB leaves ONE per CU: 64->256 @64x32 65 instead of 58 us, profiles/r05_conv_bench_1x1_*.txt)
+    'side_batch': 1,             # backward plan: weight-gradient launches issued per fork onto the side stream (0: one stream)
+    'graph_side_batch': 0,       # the same for a step captured into a hipGraph (every cross-stream edge costs at replay; 0 measured best)
+    's1_bigtile_branches': 2,    # branch count of the module steps that take 256-pixel tiles (3 measured 32.2 instead of 30.5 ms per step)
+    's1_tstore': 1,              # 0 = no transposed forward epilogue, 2 = also with BatchNorm statistics (13 % slower there)
 }
 for _kv in filter(None, os.environ.get('BPB_TUNE', '').split(',')):      # measurement hook: BPB_TUNE=wgrad16_blocks=384,wgrad16_tpb=8
     _k, _v = _kv.split('=')
@@ -204,26 +209,33 @@ class Net:
         self.grad_writers = []     # (Rec, [gradient tensors it writes]): which backward launch completes which parameter gradient
         self.grouped = os.environ.get('BPB_GROUPED', '1') != '0'        # 0: one launch per record (measurement aid)
         self.use_s1 = os.environ.get('BPB_CONV_S1', '1') != '0'         # 0: every convolution on the general kernel
-        self.use_wgrad16 = os.environ.get('BPB_WGRAD16', '1') != '0'    # 0: every weight gradient on the first-generation kernel
-        self.use_wgrad1x1 = os.environ.get('BPB_WGRAD1X1', '1') != '0'  # 0: 1x1 weight gradients on the first-generation kernel
-        self.relu_bits = os.environ.get('BPB_RELU_BITS', '1') != '0'    # 0: the backward passes re-read the fuse output for the ReLU mask
-        self.merge_identity = os.environ.get('BPB_MERGE_IDENTITY', '1') != '0'
-        self.fold_eval_bn = os.environ.get('BPB_FOLD_EVAL_BN', '1') != '0'
+        # plan policies whose A/B is settled (rounds 2-4, profiles/r0*_ab_*): plain attributes for the tests and measurement tools,
+        # no longer environment switches -- a switch is an untested product configuration
+        self.use_wgrad16 = True        # False: every weight gradient on the first-generation kernel
+        self.use_wgrad1x1 = True       # False: 1x1 weight gradients on the first-generation kernel
+        self.relu_bits = True          # False: the backward passes re-read the fuse output for the ReLU mask
+        self.merge_identity = True     # the gradient of a block's identity term rides in the BatchNorm-backward apply pass of its last convolution
+        self.fold_eval_bn = True       # eval plan: BatchNorm folded into the packed weights (scale) and the convolution epilogue (shift, ReLU)
         self.dgrad_bn_partials = os.environ.get('BPB_DGRAD_BN', '1') != '0'    # BatchNorm-backward partials from the dgrad epilogue
         self.use_pw = os.environ.get('BPB_CONV_PW', '1') != '0'                # 0: pointwise convolutions with K <= 256 on bpb_conv_s1 instead of bpb_conv_pw
         self.debug_pw = []
         self.pw_min_pixels = 8192      # fewer pixels: not enough 32-pixel tiles for a one-generation persistent grid (tests lower it)
-        self.use_s1w = os.environ.get('BPB_CONV_S1W', '1') != '0'              # 0: strided 3x3 data gradients on the general kernel
-        self.use_s1_1x1s2 = os.environ.get('BPB_S1_1X1_STRIDE2', '1') != '0'    # 0: data gradient of 1x1 stride-2 convolutions as parity classes of the general kernel
-        self.use_conv_c4 = os.environ.get('BPB_CONV_C4', '1') != '0'             # 0: stem forward on the general kernel
+        self.use_s1w = True            # False: strided 3x3 data gradients on the general kernel
+        self.use_s1_1x1s2 = True       # False: data gradient of 1x1 stride-2 convolutions as parity classes of the general kernel
+        self.use_conv_c4 = True        # False: stem forward on the general kernel
         self.debug_c4 = []
-        self.tune_1x1 = os.environ.get('BPB_S1_1X1_TILES', '1') != '0'         # 0: round-3 tile rule for stand-alone 1x1 convolutions
-        self.use_wgrad_c4 = os.environ.get('BPB_WGRAD_C4', '1') != '0'         # 0: stem weight gradients on the first-generation kernel
-        self.eval_residual_epilogue = os.environ.get('BPB_EVAL_RES', '1') != '0'   # eval plan: residual adds in the conv epilogue
+        self.tune_1x1 = True           # False: round-3 tile rule for stand-alone 1x1 convolutions
+        self.use_wgrad_c4 = True       # False: stem weight gradients on the first-generation kernel
+        self.eval_residual_epilogue = True   # eval plan: residual adds in the conv epilogue
+        self.xcd_map = True            # XCD-aware block -> tile maps of conv_s1 / conv_s1w / conv_pw / wgrad16
+        self.s1_nopad = True           # the halo of a problem whose padding alone costs the launch a workgroup per CU is staged unpadded
+        self.s1_stride2 = True         # stride-2 forward convolutions on the lean kernel
+        self.multi_concat_enabled = True     # the HRNet head concatenation as one launch
+        self.defer_reduce = True       # the slab reduces of a fork region launched together at its end
         self.bn_momentum = BN_MOMENTUM     # running-statistics momentum of every BatchNorm of this plan
         # weight-gradient launches (+ their slab reduces) of the backward plan on a second stream (csrc/plan.cpp: bpb_plan_run2)
         self.side_stream = os.environ.get('BPB_SIDE_STREAM', '1') != '0'
-        self.side_batch = int(os.environ.get('BPB_SIDE_BATCH', '1'))           # side records per fork of bpb_plan_run2 (0: one stream)
+        self.side_batch = TUNE['side_batch']      # side records per fork of bpb_plan_run2 (0: one stream)
         self._side = None                  # (torch stream, fork event, join event), created on first use
 
     # ------------------------------------------------------------------ graph construction
@@ -385,7 +397,7 @@ class Net:
                 # A TWO-branch module step (HRNet stage 2: 32 channels at 64x32 + 64 channels at 32x16) is 1536 workgroups of 128
                 # pixels on 1024 slots -- one and a half generations, 83 TFLOP/s against 98 / 108 for the three- / four-branch steps
                 # (gpurun_out/r04d plan timing).  With 256-pixel tiles it is ONE generation of 768 workgroups on 768 slots.
-                if str(nbranch) in os.environ.get('BPB_S1_BIGTILE_BRANCHES', '2').split(',') and stride == 1 and wgs(2, 1, 0) >= 256:
+                if nbranch == TUNE['s1_bigtile_branches'] and stride == 1 and wgs(2, 1, 0) >= 256:
                     mt_r = 2
                 # (round 3's mixed-tile variant -- two pixel sub-tiles per wave for the shallow wide branches inside the same launch --
                 #  measured -6 % / -2 % / 0 % on the two- / three- / four-branch launches, profiles/r03_s1_mixed_first.txt: removed)
@@ -447,7 +459,7 @@ class Net:
         p.stats = None
         p.N, p.H, p.W, p.Cin, p.Cout, p.R = n, h, w, cin, cout, r
         p.S, p.Hi, p.Wi = stride, hi, wi
-        p.xr = 1 if os.environ.get('BPB_XCD_MAP', '1') != '0' else 0
+        p.xr = 1 if self.xcd_map else 0
         p.lTI, p.lTH, p.lTW = _log2(ti), _log2(th), _log2(tw)
         p.HH, p.HW, p.CK, p.LD = hh, hw, ck, ck + 4
         # The 4-float padding of a halo pixel keeps the A-fragment reads free of bank conflicts.  A grouped launch allocates the
@@ -456,7 +468,7 @@ class Net:
         # three instead of four workgroups per CU (tools/s1_trace.py) -- that problem stages its halo unpadded.
         quarter = 160 * 1024 // 4
         lds_of = lambda ld_: 2 * ((ti * hh * hw * (ld_ // 4) + 3) // 4 * 4 + t * (ck // 4) * ntc) * 16
-        if lds_of(ck + 4) > quarter >= lds_of(ck) and os.environ.get('BPB_S1_NOPAD', '1') != '0':
+        if lds_of(ck + 4) > quarter >= lds_of(ck) and self.s1_nopad:
             p.LD = ck
         p.tiles_a, p.tiles_b = _cdiv(h, th), _cdiv(w, tw)
         p.n_mtiles = _cdiv(n, ti) * p.tiles_a * p.tiles_b
@@ -471,7 +483,7 @@ class Net:
         # store through an LDS transpose (16-byte stores, csrc/conv_s1.hip).  With the statistics the per-channel sums want the MFMA
         # layout (a lane owns a channel): the transposed form then pays pixel-validity arithmetic and a barrier on top and measured
         # 13 % SLOWER on the three-branch launches of the training plan (BPB_S1_TSTORE=2 forces it there, profiles/r03_*).
-        ts = os.environ.get('BPB_S1_TSTORE', '1')
+        ts = str(TUNE['s1_tstore'])
         p.tstore = 1 if (ts != '0' and (mt_r, nt) == (1, 1) and not accumulate and not wflip and (stats is None or ts == '2')
                          and lds_of(p.LD) >= 2 * 16384) else 0
         if stats is not None:
@@ -510,7 +522,7 @@ class Net:
         p.n_mtiles = max(1, min(_cdiv(tiles, 4), (256 * per_cu) // n_nt))
         p.ntiles32 = tiles
         p.blk_begin, p.accumulate, p.relu = 0, accumulate, relu
-        p.xr = 1 if os.environ.get('BPB_XCD_MAP', '1') != '0' else 0
+        p.xr = 1 if self.xcd_map else 0
         p.x_bytes, p.w_bytes, p.y_bytes = x_buf.numel() * 4, w_packed.numel() * 4, y_buf.numel() * 4
         if stats is not None:
             st_buf = torch.empty(p.n_mtiles * 2 * cout, device=self.device, dtype=torch.float64)
@@ -556,7 +568,7 @@ class Net:
         p.n_mtiles = _cdiv(n, ti) * p.tiles_a * p.tiles_b
         p.n_ntiles = _cdiv(cout, 32)
         p.blk_begin, p.accumulate = 0, accumulate
-        p.xr = 1 if os.environ.get('BPB_XCD_MAP', '1') != '0' else 0
+        p.xr = 1 if self.xcd_map else 0
         p.x_bytes, p.w_bytes, p.y_bytes = dy_buf.numel() * 4, w_packed.numel() * 4, dx_buf.numel() * 4
         p.magic_spp, p.magic_hw, p.magic_hh = magic(p.LD // 4), magic(hw), magic(hh)
         p.magic_nt, p.magic_tb, p.magic_ta = magic(p.n_ntiles), magic(p.tiles_b), magic(p.tiles_a)
@@ -779,7 +791,7 @@ class Net:
                             pl.add(c4_rec(cv.wf, y.buf, None, None, 0))
                         continue
                     stats.append(c4_stats)
-                elif self.use_s1 and cv.is_s1_fwd and (cv.stride == 1 or os.environ.get('BPB_S1_STRIDE2', '1') != '0'):
+                elif self.use_s1 and cv.is_s1_fwd and (cv.stride == 1 or self.s1_stride2):
                     prob = self.s1_problem(x.buf, (x.N, x.H, x.W), cv.wf, y.buf, x.C, y.C, cv.R, bias=cv.bias, stats=stats,
                                            in_region=region != 0, stride=cv.stride, nbranch=self._region_slots().get(region, 0))
                 if prob is None and not c4:
@@ -948,7 +960,7 @@ class Net:
     def multi_concat(self, out, srcs, c0):
         """One launch for the whole concatenation (csrc/resample.hip: bpb_bilinear_concat_multi_*)?"""
         return (len(srcs) >= 2 and c0 == 0 and len(srcs) <= 8 and all(a.C % 4 == 0 for a in srcs) and
-                sum(a.C for a in srcs) == out.C and os.environ.get('BPB_MULTI_CONCAT', '1') != '0')
+                sum(a.C for a in srcs) == out.C and self.multi_concat_enabled)
 
     def _bilinear_args(self, src_buf, dst_buf, a, out, c0, accumulate=0):
         ba = BilinearArgs()
@@ -1127,7 +1139,7 @@ class Net:
     # ------------------------------------------------------------------ backward plan
     def _flush_reduce(self, bwd):
         """Emit the collected slab-reduce records as one unit (launched together, <= 16 per launch) on slot 0."""
-        if self._pending_reduce and os.environ.get('BPB_DEFER_REDUCE', '1') != '0':
+        if self._pending_reduce and self.defer_reduce:
             tag = ('wgr', id(self._pending_reduce[0]))
             for r in self._pending_reduce:
                 r.together = tag
@@ -1403,7 +1415,7 @@ class Net:
             wp.magic_hw, wp.magic_hh = magic(wp.HW), magic(wp.HH)
             blk16, tpb16 = TUNE['wgrad16_blocks'], TUNE['wgrad16_tpb']
             wp.nsplit = max(1, min(_cdiv(wp.n_mtiles, tpb16), _cdiv(blk16, pairs)))
-            wp.xr = 1 if os.environ.get('BPB_XCD_MAP', '1') != '0' else 0
+            wp.xr = 1 if self.xcd_map else 0
             elems = wp.nsplit * t * x.C * cout
         # 1x1 stride-1 filters with >= 64 channels on both sides: csrc/wgrad1x1.hip streams x and dy once through a
         # (64|128|256) x (256|128|64) channel tile per workgroup; the tile shape minimises the operand re-reads

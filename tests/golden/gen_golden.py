@@ -78,21 +78,27 @@ def ref_combined_loss(out, pids, masks, weights, use_vis):
     return loss + weights['pixls']['ce'] * bpa, summ, bpa
 
 
-def dump_outputs(store, prefix, out):
+def dump_outputs(store, prefix, out, slim=0):
+    """slim > 0 (the batch-64 fixture of the headline configuration: the full dump would be ~150 MB): every 4th feature of the
+    embeddings, every 8th class of the identity scores, pixel scores / masks of the first `slim` images, a 53x sparser sub-sample of the spatial features; everything else
+    (visibility, spatial sub-sample, losses, gradient digests, running statistics, the eval ranking) complete."""
     emb, vis, ids, pix, sp, mk = out
+    fe = (lambda t: t[..., ::4]) if slim else (lambda t: t)
+    fi = (lambda t: t[..., ::8]) if slim else (lambda t: t)
+    fn = (lambda t: t[:slim]) if slim else (lambda t: t)
     for k, v in emb.items():
-        store['%s/emb/%s' % (prefix, k)] = C.to_np(v)
+        store['%s/emb/%s' % (prefix, k)] = C.to_np(fe(v))
     for k, v in vis.items():
         store['%s/vis/%s' % (prefix, k)] = C.to_np(v)
     for k, v in ids.items():
-        store['%s/ids/%s' % (prefix, k)] = C.to_np(v)
+        store['%s/ids/%s' % (prefix, k)] = C.to_np(fi(v))
     if pix is not None:
-        store['%s/pix' % prefix] = C.to_np(pix)
-    store['%s/sp_sub' % prefix] = C.to_np(C.subsample(sp))
+        store['%s/pix' % prefix] = C.to_np(fn(pix))
+    store['%s/sp_sub' % prefix] = C.to_np(C.subsample(sp, 61 * 53 if slim else 61))
     store['%s/sp_chan_mean' % prefix] = C.to_np(sp.mean(dim=(0, 2, 3)))
-    store['%s/mask_parts' % prefix] = C.to_np(mk['parts'])
-    store['%s/mask_foreg' % prefix] = C.to_np(mk['foreg'])
-    store['%s/mask_backg' % prefix] = C.to_np(mk['backg'])
+    store['%s/mask_parts' % prefix] = C.to_np(fn(mk['parts']))
+    store['%s/mask_foreg' % prefix] = C.to_np(fn(mk['foreg']))
+    store['%s/mask_backg' % prefix] = C.to_np(fn(mk['backg']))
 
 
 MODEL_CASES = {
@@ -103,6 +109,8 @@ MODEL_CASES = {
     'hrw8_k3_shared': ('hrnet_w8', 3, 64, 8, 64, 32, 16, {'shared_parts_id_classifier': True}),
     'hr32_k5': ('hrnet32', 5, 512, 16, 128, 64, 16, {}),
     'hr32_k5_full': ('hrnet32', 5, 512, 8, 256, 128, 751, {}),
+    # round 5: BASELINE configs[2] at its REAL batch (the headline configuration of bench.py); slim dump (dump_outputs)
+    'hr32_k5_n64': ('hrnet32', 5, 512, 64, 256, 128, 751, {'_slim': 8}),
     'r50_k2': ('resnet50', 2, 512, 16, 128, 64, 16, {}),
     'r50_k5_full': ('resnet50', 5, 512, 8, 256, 128, 751, {}),
     'hr48_k8': ('hrnet48', 8, 512, 8, 192, 64, 16, {}),
@@ -149,8 +157,10 @@ def eval_distance(out, dt):
 def gen_model(name):
     from torchreid import models
     backbone, k, d, n, h, w, ncls, extra = MODEL_CASES[name]
+    extra = dict(extra)
+    slim = extra.pop('_slim', 0)
     imgs, masks, pids = C.synth_batch(n, h, w, k, ncls)
-    store = {'meta': np.array([k, d, n, h, w, ncls])}
+    store = {'meta': np.array([k, d, n, h, w, ncls]), 'slim': np.array(slim)}
     for dt, tag in ((torch.float32, 'f32'), (torch.float64, 'f64')):
         torch.manual_seed(0)
         model = models.build_model('bpbreid', num_classes=ncls, loss='part_based', pretrained=False,
@@ -159,7 +169,7 @@ def gen_model(name):
         model = model.to(dt)
         model.train()
         out = model(imgs.to(dt), external_parts_masks=masks.to(dt))
-        dump_outputs(store, tag + '/train', out)
+        dump_outputs(store, tag + '/train', out, slim)
         float_vis = extra.get('training_binary_visibility_score', True) is False
         # The reference's triplet loss cannot run in fp64 ((~mask).float()*finfo(f64).max overflows to inf,
         # part_averaged_triplet_loss.py:145): the fp64 arbiter evaluates the LOSS in fp32 on the fp64 model
@@ -196,7 +206,7 @@ def gen_model(name):
         model.eval()
         with torch.no_grad():
             out = model(imgs.to(dt), external_parts_masks=masks.to(dt))
-        dump_outputs(store, tag + '/eval', out)
+        dump_outputs(store, tag + '/eval', out, slim)
         dm, order = eval_distance(out, dt)
         store[tag + '/eval/distmat'], store[tag + '/eval/argsort'] = dm, order
     np.savez_compressed(os.path.join(HERE, 'model_%s.npz' % name), **store)

@@ -536,9 +536,9 @@ def test_full_backbones_forward_backward():
 def test_maxpool_and_bilinear_concat(multi, monkeypatch):
     """multi = 1: the whole concatenation in one launch (+ per-channel statistics partials) and the separable backward;
     multi = 0: one launch per source, one-pass gather backward."""
-    monkeypatch.setenv('BPB_MULTI_CONCAT', multi)
     g = torch.Generator().manual_seed(5)
     net = Net(DEV)
+    net.multi_concat_enabled = multi == '1'
     x = torch.randn(3, 16, 13, 9, generator=g)
     xa = Act(net, 3, 13, 9, 16)
     xa.buf.copy_(nhwc(x))
@@ -768,6 +768,39 @@ def test_part_distance_large_ranking_identical_to_oracle():
     a = evaluate_rank(dm.numpy(), pids_q, pids_g, cq, cg)
     b = OM.evaluate_rank(dm_ref.numpy(), pids_q, pids_g, cq, cg)
     assert np.allclose(a['cmc'], b['cmc'], atol=1e-6) and abs(a['mAP'] - b['mAP']) < 1e-6
+
+
+def test_individual_parts_ranking_on_the_gpu_equals_the_oracle_per_slice():
+    """engine.individual_parts_ranking (part_based_engine.py:308-339): every [Q, G] slice of the per-part matrix ranked on its own --
+    on the GPU from the matrix in HBM, equal to the oracle's evaluate_rank on the same slice (and to the host path)."""
+    from bpbreid_amd.engine import ImagePartBasedEngine
+
+    class _M(torch.nn.Module):
+        parts_num = 5
+
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(1, device=DEV))
+    eng = ImagePartBasedEngine(_M(), test_embeddings=('bn_foreg', 'parts'))
+    g = torch.Generator().manual_seed(99)
+    q, G, p, d = 96, 1500, 6, 64
+    qf = F.normalize(torch.randn(q, p, d, generator=g), dim=-1).to(DEV)
+    gf = F.normalize(torch.randn(G, p, d, generator=g), dim=-1).to(DEV)
+    qv, gv = (torch.rand(q, p, generator=g) < 0.8).to(DEV), (torch.rand(G, p, generator=g) < 0.8).to(DEV)
+    qv[:, 0], gv[:, 0] = True, True
+    pq, pg = torch.randint(0, 120, (q,), generator=g).numpy(), torch.randint(0, 120, (G,), generator=g).numpy()
+    cq, cg = torch.randint(0, 6, (q,), generator=g).numpy(), torch.randint(0, 6, (G,), generator=g).numpy()
+    cmc, mAP, dm, parts = eng.evaluate(qf, gf, qv, gv, pq, pg, cq, cg, return_body_parts_distmat='device')
+    assert parts.is_cuda and tuple(parts.shape) == (p, q, G)
+    rows = eng.individual_parts_ranking(parts, pq, pg, cq, cg)
+    rows_host = eng.individual_parts_ranking(parts.cpu(), pq, pg, cq, cg)
+    assert [r[0] for r in rows] == ['foreg', 'p 0', 'p 1', 'p 2', 'p 3', 'p 4']
+    for k, (row, rh) in enumerate(zip(rows, rows_host)):
+        ref = OM.evaluate_rank(parts[k].cpu().numpy(), pq, pg, cq, cg)
+        assert abs(row[1] - ref['mAP']) < 1e-6 and abs(row[2] - ref['cmc'][0]) < 1e-6 and abs(row[3] - ref['cmc'][4]) < 1e-6
+        assert abs(row[4] - ref['cmc'][9]) < 1e-6 and np.allclose(row[1:], rh[1:], atol=1e-6)
+    _, _, _, host_parts = eng.evaluate(qf, gf, qv, gv, pq, pg, cq, cg, return_body_parts_distmat=True)
+    assert not host_parts.is_cuda and torch.equal(host_parts, parts.cpu())
 
 
 def test_gpu_argsort_is_the_stable_argsort_of_numpy_and_of_the_host_routine():

@@ -25,7 +25,7 @@ DEV = torch.device('cuda', 0)
 # Gradient digests are only asserted element-wise on the well-conditioned fixtures.  On the tiny 64x32 / 128x64 inputs
 # one near-tie flip of the (non-differentiable) arg-max part under fp32 round-off moves 1/1024 of the data, and
 # BatchNorm populations of 4..32 elements amplify round-off: there the check is a cosine over all sampled elements.
-WELL_CONDITIONED = ('hr32_k5', 'hr32_k5_full', 'r50_k5_full', 'hr48_k8', 'hrw16_k5_float_vis', 'hrw16_k3_shared', 'hrw16_k5_soft',
+WELL_CONDITIONED = ('hr32_k5', 'hr32_k5_full', 'hr32_k5_n64', 'r50_k5_full', 'hr48_k8', 'hrw16_k5_float_vis', 'hrw16_k3_shared', 'hrw16_k5_soft',
                     'hrw16_k5_hard', 'hrw16_k5_nolearn', 'hrw16_k5_before', 'hrw16_k5_gap', 'hrw16_k5_gmp',
                     # round 4: the 256x128 ResNet-50 K=2 fixtures measure 0-2 of ~180 parameters outside the contract bound, none outside
                     # the wide one, median error 0.8-1.5x the reference's noise -- held to the same rule (the loose rule below is left
@@ -39,6 +39,7 @@ MODEL_CASES = {
     'r50_k2': ('resnet50', {}),
     'hr48_k8': ('hrnet48', {}),
     'hr32_k5_full': ('hrnet32', {}),
+    'hr32_k5_n64': ('hrnet32', {}),        # round 5: BASELINE configs[2] at its real batch of 64 (slim dump: gen_golden.dump_outputs)
     'r50_k5_full': ('resnet50', {}),
     'hrw8_k5_soft': ('hrnet_w8', {'test_use_target_segmentation': 'soft'}),
     'hrw8_k5_hard': ('hrnet_w8', {'test_use_target_segmentation': 'hard'}),
@@ -70,7 +71,7 @@ WEIGHTS_DEFAULT = {'globl': {'id': 1., 'tr': 0.}, 'foreg': {'id': 1., 'tr': 0.},
 # BatchNorm over a handful of values amplifies round-off by 1/sigma and the bound is 3x wider.  The eval-only 'soft' / 'hard'
 # target-segmentation fixtures apply running statistics of train-mode embeddings to differently masked eval embeddings: dead
 # ReLU features (running variance ~0) amplify the difference by 1/sqrt(eps) = 316, same wider bound.
-TIGHT = ('hr32_k5', 'hr32_k5_full', 'r50_k2', 'r50_k5_full', 'hr48_k8', 'r50_k2_nolearn', 'r50_k2_before', 'r50_k2_before_after',
+TIGHT = ('hr32_k5', 'hr32_k5_full', 'hr32_k5_n64', 'r50_k2', 'r50_k5_full', 'hr48_k8', 'r50_k2_nolearn', 'r50_k2_before', 'r50_k2_before_after',
          'hrw16_k5_float_vis', 'hrw16_k3_shared', 'hrw16_k5_soft', 'hrw16_k5_hard', 'hrw16_k5_nolearn', 'hrw16_k5_before', 'hrw16_k5_gap',
          'hrw16_k5_gmp')
 
@@ -87,6 +88,12 @@ def close(got, ref32, ref64, c=4.0, rel=1e-4, what=''):
 
 def check_outputs(z, tag32, tag64, out, c=4.0, rel=1e-4, rel_bn=None):
     emb, vis, ids, pix, sp, mk = out
+    slim = int(z['slim']) if 'slim' in z.files else 0
+    if slim:        # the batch-64 fixture stores every 4th feature, every 8th class, the maps of the first `slim` images
+        emb = {k: v[..., ::4] for k, v in emb.items()}
+        ids = {k: v[..., ::8] for k, v in ids.items()}
+        pix = pix[:slim] if pix is not None else None
+        mk = {k: v[:slim] for k, v in mk.items()}
     kw = dict(c=c, rel=rel)
     # rel_bn: tolerance of everything behind a BatchNorm1d over the (8-sample) batch in the configuration-branch fixtures
     kb = dict(c=c, rel=rel if rel_bn is None else rel_bn)
@@ -105,7 +112,7 @@ def check_outputs(z, tag32, tag64, out, c=4.0, rel=1e-4, rel_bn=None):
     else:
         assert pix is None
     if sp is not None:       # (None: the model was told not to materialise the concatenated map -- head on the branch outputs)
-        close(Cm.to_np(Cm.subsample(sp.contiguous())), z[tag32 + '/sp_sub'], z[tag64 + '/sp_sub'], what='spatial', **kw)
+        close(Cm.to_np(Cm.subsample(sp.contiguous(), 61 * 53 if slim else 61)), z[tag32 + '/sp_sub'], z[tag64 + '/sp_sub'], what='spatial', **kw)
     close(Cm.to_np(mk['parts']), z[tag32 + '/mask_parts'], z[tag64 + '/mask_parts'], what='masks', **kw)
     close(Cm.to_np(mk['foreg']), z[tag32 + '/mask_foreg'], z[tag64 + '/mask_foreg'], what='fg mask', **kw)
     ref_bg = z[tag32 + '/mask_backg']
@@ -244,19 +251,16 @@ def test_model_matches_reference_golden(name, lowres, golden_dir):
         assert len(bad) == 0, (len(bad), len(digests), bad[:6])
         assert 1.0 - cosine <= max(1e-4, 2.0 * (1.0 - cosine_ref)), (cosine, cosine_ref)
     else:
-        # 64x32 fixtures (feature maps down to 2x1 pixels, BatchNorm populations of 8..32 values) and the small ResNet ones: one
-        # arg-max / ReLU flip moves 1/1024 of the data, so individual parameters are chaotic at fp32 (measured, round 3:
-        # 10-46 % of the hrnet_w8 parameters and 0-1 % of the ResNet-50 ones outside the per-parameter contract bound, <= 0.7 %
-        # outside the wide bound, median error 0.8-7.2x the reference's own fp32 noise).  Bounded in aggregate, never by the
-        # cosine alone: direction relative to the reference's own fp32 run, typical error relative to its noise, the wide bound
-        # for 99 % of the parameters.  (Round 4, tests/golden/noise_control.py CONTROL=stem_taps: the REFERENCE with nothing but the
-        # summation order of its stem convolution changed lands at median err / noise 9.4 with 53 of 985 parameters outside the wide
-        # bound on hrw8_k5 -- and at 1.2 / none on the well-conditioned hrw16 fixture; noise_control_r04.txt.  These bounds hold
-        # because csrc/conv_c4.hip keeps the summation order of the kernel it replaced, not because the order is better than another.)
+        # 64x32 hrnet_w8 fixtures (feature maps down to 2x1 pixels, BatchNorm populations of 8..32 values): NOT a precision tier.
+        # One arg-max / ReLU flip moves 1/1024 of the data, individual parameters are chaotic at fp32 -- the REFERENCE with nothing
+        # but the summation order of its stem changed lands at a median of 9.4x its own noise with 53 of 985 parameters outside the
+        # wide bound here (tests/golden/noise_control.py CONTROL=stem_taps, noise_control_r04.txt), so a numeric per-parameter
+        # bound on these fixtures can only hide or fake regressions (review of round 4).  What they are for: the tiny-map code
+        # paths (general convolution kernel, 2x1 tiles) through forward, loss and backward -- outputs and loss are asserted above
+        # at their own bounds; of the gradients only what is stable is asserted: the direction relative to the reference's own
+        # fp32 run and the wide bound for 99 % of the parameters.  Every configuration branch has a 128x64 twin under the strict rule.
         assert 1.0 - cosine <= max(1e-4, 2.0 * (1.0 - cosine_ref)), (cosine, cosine_ref)
-        assert med <= 10.0, med
         assert len(bad) <= 0.01 * len(digests), (len(bad), len(digests), bad[:6])
-        assert len(loose) <= 0.5 * len(digests), (len(loose), len(digests))
     sd = model.state_dict()
     rs = [kk for kk in sd if kk.endswith('running_mean') or kk.endswith('running_var')]
     got = np.array([float(sd[kk].double().sum()) for kk in rs])

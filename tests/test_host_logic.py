@@ -213,8 +213,9 @@ def test_standalone_1x1_convolutions_take_128_pixel_tiles_where_every_cu_still_g
     """Plan-time tile rule of 1x1 launches that stand alone (ResNet-50 layers 2-4, profiles/r04_s1_sweep_1x1.txt): 128 pixels x 64
     channels with 32-channel chunks where the convolution narrows (K >= 256), 128 x 128 where it widens by 4; the round-3 tile at
     small batches (too few workgroups), inside fork regions (one kernel variant per grouped launch) and with the switch off."""
-    def tile(n, h, w, cin, cout, region=False, pw=False):
+    def tile(n, h, w, cin, cout, region=False, pw=False, tuned=True):
         net = Net(torch.device('cpu'))
+        net.tune_1x1 = tuned
         net.use_pw = pw          # (the K <= 256 shapes go to bpb_conv_pw by default: this test is about bpb_conv_s1's tile rule)
         if region:
             net.fork(2)
@@ -250,9 +251,8 @@ def test_standalone_1x1_convolutions_take_128_pixel_tiles_where_every_cu_still_g
     assert tile(64, 64, 32, 64, 64, region=True, pw=True) == (0, 2) and tile(4, 16, 8, 64, 64, pw=True) == (0, 1)
     assert tile(8, 16, 8, 1024, 256) == (1, 1, 2, 32)         # batch 8: 32 workgroups of the large tile -> not used
     assert tile(64, 16, 8, 1024, 256, region=True) == (1, 1, 2, 32)
-    monkeypatch.setenv('BPB_S1_1X1_TILES', '0')
-    assert tile(64, 16, 8, 1024, 256) == (1, 1, 2, 32)
-    assert tile(64, 16, 8, 512, 2048) == (2, 1, 2, 16)
+    assert tile(64, 16, 8, 1024, 256, tuned=False) == (1, 1, 2, 32)
+    assert tile(64, 16, 8, 512, 2048, tuned=False) == (2, 1, 2, 16)
 
 
 @pytest.mark.parametrize('case', CONV_CASES)

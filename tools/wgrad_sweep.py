@@ -24,6 +24,7 @@ def build(shapes, grouped, env):
     G.TUNE.update({k: int(v) for k, v in tune.items()})
     try:
         net = Net(dev)
+        net.use_wgrad16 = env.get('USE_WGRAD16', '1') != '0'      # (a plan attribute since round 5, no longer an environment switch)
         if grouped:
             net.fork(len(shapes))
         outs = []
@@ -64,7 +65,7 @@ def timed(net, prefix, reps=20):
     return s.elapsed_time(e) * 1e3 / reps
 
 
-CONFIGS = [('gen1', {'BPB_WGRAD16': '0'}), ('gen1 blk256', {'BPB_WGRAD16': '0', 'wgrad_blocks': '256'})]
+CONFIGS = [('gen1', {'USE_WGRAD16': '0'}), ('gen1 blk256', {'USE_WGRAD16': '0', 'wgrad_blocks': '256'})]
 for blk, tpb in itertools.product(('512', '256', '128', '64'), ('2', '4', '8')):
     CONFIGS.append(('g2 blk%s tpb%s' % (blk, tpb), {'wgrad16_blocks': blk, 'wgrad16_tpb': tpb}))
 
