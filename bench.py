@@ -47,6 +47,7 @@ def parse():
                     'when that does not finish inside its time budget)')
     ap.add_argument('--no-forward-only', action='store_true')
     ap.add_argument('--no-eval', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip the second-class legs (ResNet-50 K=5; HRNet-W48 K=8 at 384x128)')
     ap.add_argument('--graph', type=int, default=-1,
                     help='1: replay the step from one hipGraph (with --gpus N the RCCL all-reduce launches are captured with the step '
                          'and the ranks AGREE on graph vs eager); 0: eager launches of the taped step (bpbreid_amd.fused_step: one '
@@ -213,7 +214,8 @@ def cpu_baseline(args):
     return cpu_train_leg(args.backbone, args.parts, args.height, args.width, args.classes, args.cpu_batch or 16, warm, timed, args.batch)
 
 
-PMC_FILE = 'profiles/r04_pmc_hbm.json'
+PMC_FILE = 'profiles/r05_pmc_hbm.json'
+INSTEP_FILE = 'profiles/r05_bench_kernel_in_step.json'      # tools/rocprof_summary.py: kernel-trace averages of the two-stream step
 
 
 def pmc_traffic(sym):
@@ -238,6 +240,53 @@ def pmc_traffic(sym):
         return {'traffic': None}
     return {'traffic': row['hbm_bytes_per_launch'],
             'traffic_source': '%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, build %s)' % (PMC_FILE, want)}
+
+
+def in_step_duration(sym):
+    """Average duration (us) of kernel `sym` INSIDE the real two-stream step, from the committed rocprofv3 --kernel-trace summary of
+    this same command (INSTEP_FILE), or None when that file was taken on another build.  The live figure of this run
+    (`frac_alone`: every launch alone on the stream between HIP events) is what the kernel does by itself; inside the step the
+    data-gradient launches share the CUs with the weight gradients of the side stream and stretch."""
+    from bpbreid_amd.build import source_id
+    norm = lambda s_: s_.replace('void ', '').split('(')[0].replace(' ', '')
+    try:
+        table = json.load(open(os.path.join(ROOT, INSTEP_FILE)))
+    except Exception:
+        return None, 'no %s' % INSTEP_FILE
+    have, want = table.get('_build', {}).get('source_id'), source_id()
+    if have != want:
+        return None, '%s is from build %s, this is %s: not quoted' % (INSTEP_FILE, have, want)
+    row = table.get(norm(sym))
+    return (row['average_us'], '%s (rocprofv3 --kernel-trace of the two-stream step, build %s)' % (INSTEP_FILE, want)) if row else (None, 'kernel not in %s' % INSTEP_FILE)
+
+
+def extra_leg(backbone, parts, height, width, batch, classes, dev, steps=10, warm=3):
+    """A second-class configuration timed the same way after the headline run (BASELINE configs[1] and the single-GPU slice of
+    configs[4]): the taped train step on synthetic data resident in HBM, `steps` timed steps."""
+    import common as Cm
+    from bpbreid_amd.model import bpbreid
+    from bpbreid_amd.engine import ImagePartBasedEngine
+    from bpbreid_amd.optim import FusedAdam
+    cfg = Cm.make_cfg(backbone, parts, 512)
+    model = Cm.fill_state_dict_(bpbreid(classes, config=cfg, pretrained=False)).to(dev)
+    eng = ImagePartBasedEngine(model, optimizer=FusedAdam(model, lr=3.5e-4, weight_decay=5e-4), losses_weights=WEIGHTS, mask_filtering_training=True)
+    imgs, masks, pids = Cm.synth_batch(batch, height, width, parts, classes, seed=4321)
+    data = {'image': imgs.to(dev), 'mask': masks.to(dev), 'pid': pids.to(dev)}
+    for _ in range(warm):
+        loss, _ = eng.forward_backward(data)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, _ = eng.forward_backward(data)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    lost = sum(pl.net.split_timeouts() for pl in model._plans.values())
+    out = {'workload': '%s K=%d parts, %dx%d, batch %d' % (backbone, parts, height, width, batch), 'ms_per_step': ms,
+           'images_per_s': 1e3 * batch / ms, 'steps': steps, 'final_loss': float(loss.detach()), 'taped_step': eng.fused_reason is None,
+           'k_split_timeouts': lost}
+    del eng, model, data
+    torch.cuda.empty_cache()
+    return out
 
 
 def pin_rank_to_cores(local, nranks):
@@ -296,6 +345,13 @@ def roofline(model, plan):
         achieved = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
         r = {'bound': 'mfma', 'kernel': sym, 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
              'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None}
+        # `frac` = frac_alone: every launch alone between HIP events on the launch stream (reproducible from the one-stream
+        # rocprofv3 summary profiles/*_bench_kernel_stats_one_stream.csv); frac_in_step: the same FLOPs over the kernel's average
+        # duration inside the two-stream step (profiles/*_bench_kernel_stats.csv), where it shares the chip with the weight gradients
+        r['frac_alone'] = r['frac']
+        us, src = in_step_duration(sym)
+        r['frac_in_step'] = (dom['flops'] / dom['launches'] / (us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS) if us else None
+        r['frac_in_step_source'] = src
     else:
         achieved = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
         r = {'bound': 'hbm', 'kernel': sym, 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
@@ -586,6 +642,15 @@ def main():
             result['eval'] = eval_block(dev)
         except Exception as ex:                          # a secondary figure: never lose the bench line over it
             result['eval'] = {'error': repr(ex)}
+    if rank == 0 and world == 1 and not args.no_extra and args.backbone == 'hrnet32':
+        # second-class configurations, driver-observed: BASELINE configs[1] (ResNet-50 K=5) and the one-GPU slice of configs[4]
+        # (HRNet-W48 K=8 at 384x128), 10 timed steps each AFTER the timed region of the headline metric
+        result['extra'] = {}
+        for key, leg in (('resnet50_k5', ('resnet50', 5, 256, 128)), ('hrnet48_k8_384x128', ('hrnet48', 8, 384, 128))):
+            try:
+                result['extra'][key] = extra_leg(leg[0], leg[1], leg[2], leg[3], args.batch, args.classes, dev)
+            except Exception as ex:                      # secondary figures: never lose the bench line over them
+                result['extra'][key] = {'error': repr(ex)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline_subprocess(args)
     if rank == 0:

@@ -26,7 +26,7 @@ def source_id():
     import hashlib
     h = hashlib.sha256()
     # (+ the plan compiler and the model glue: tile / split / stream policies decide how many bytes a launch moves)
-    policy = [os.path.join(HERE, f) for f in ('graph.py', 'model.py', 'backbones.py', 'native.py')]
+    policy = [os.path.join(HERE, f) for f in ('graph.py', 'model.py', 'backbones.py', 'native.py', 'fused_step.py', 'tape.py', 'engine.py')]
     for path in sorted([os.path.join(CSRC, s) for s in SOURCES] + policy + [os.path.join(CSRC, 'bpb_common.h'),
                                                                              os.path.join(HERE, '..', 'include', 'bpbreid_hip.h')]):
         if os.path.exists(path):
