@@ -198,29 +198,15 @@ __global__ __launch_bounds__(512, 2) void bpb_part_distance_tiled_kernel(const f
     dma_issue(0, 0, 0);
     f32x16 acc[2];
     int p = 0, ch = 0;
-    // The per-part matrix costs a 1.47 GB / P store burst per part.  Two things kept it in FRONT of the MFMAs instead of under them
-    // (round 4: 4.99 ms with the matrix against 3.96 without):
-    //  * the gallery norm of the second 32-column sub-tile was loaded between the two sub-tiles' stores, and a load waited for
-    //    behind 32 stores drains them -- the norms of a part are now fetched at the part's FIRST chunk (sixteen chunks ahead);
-    //  * __syncthreads() at the next chunk waits vmcnt(0), i.e. for the whole burst.  Stores share the vmcnt counter on gfx9 and
-    //    retire in order with the loads, so behind the epilogue of an INTERIOR tile (all 64 stores of a wave are issued: no lane
-    //    is masked off) "at most 63 outstanding" already means that the DMA of the next chunk -- issued before those stores --
-    //    has landed; the burst then drains under the next chunk's MFMAs.  Edge tiles keep the full wait.
+    // The gallery norms of a part are fetched at the part's FIRST chunk, sixteen chunks ahead of their use.  (Round 4 loaded the norm
+    // of the second 32-column sub-tile between the two sub-tiles' stores of the per-part matrix: a load waited for behind 32 stores
+    // drains them.  Same-box A/B at Q = 2048, G = 20 000, P = 9, profiles/r05_ab_distance.txt: 4.84 -> 4.63 ms with the matrix,
+    // 3.96 -> 3.81 ms without.  A counted wait -- s_waitcnt vmcnt(63) + raw s_barrier behind the 64 stores of an interior tile, so
+    // that the burst drains under the next chunk's MFMAs -- was measured too: 5.26 / 4.55 ms, the asm waits and the second loop head
+    // cost the MFMA loop more than the burst; not kept.)
     float gsv[2] = {0.f, 0.f};
-    const bool interior = q0 + 128 <= Q && g0 + 128 <= G;
-    bool stored = false;                                // the previous iteration ended a part and issued its stores
     for (int w = 0; w < nwork; ++w) {
-        if (stored) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                      // chunk w has landed; the other buffer is free
-        stored = false;
-        float qs_new = 0.f;
-        if (ch == 0) {      // (issued BEFORE the DMA of the next chunk: waiting for them does not wait for it)
-            if (!cosine && threadIdx.x < 128) qs_new = q0 + (int)threadIdx.x < Q ? qsq[(long)(q0 + threadIdx.x) * P + p] : 0.f;
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) gsv[nt] = (gcol[nt] < G && !cosine) ? gsq[(long)gcol[nt] * P + p] : 0.f;
-        }
+        __syncthreads();                                   // chunk w has landed; the other buffer is free
         if (w + 1 < nwork) {
             const bool lastc = ch + 1 == nch;
             dma_issue(lastc ? p + 1 : p, lastc ? 0 : (ch + 1) * 32, (w + 1) & 1);
@@ -230,8 +216,9 @@ __global__ __launch_bounds__(512, 2) void bpb_part_distance_tiled_kernel(const f
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-            // (every wave is past the barrier above, i.e. past the previous part's epilogue: the staged norms may be replaced)
-            if (!cosine && threadIdx.x < 128) sq_s[threadIdx.x] = qs_new;
+            if (!cosine && threadIdx.x < 128) sq_s[threadIdx.x] = q0 + (int)threadIdx.x < Q ? qsq[(long)(q0 + threadIdx.x) * P + p] : 0.f;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) gsv[nt] = (gcol[nt] < G && !cosine) ? gsq[(long)gcol[nt] * P + p] : 0.f;
         }
         const char* sb = (const char*)smem + (w & 1) * BUF;
         f32x4 a[2], b[2][2];                                // [ping-pong]([sub-tile])
@@ -264,7 +251,8 @@ __global__ __launch_bounds__(512, 2) void bpb_part_distance_tiled_kernel(const f
             __syncthreads();                                // the norms staged at the part's first chunk (nch may be 1)
             // per-part base of the output block of this tile: the lane offsets below stay 32-bit.  (Round 4 measured the per-part block
             // through an LDS transpose -- 8 sixteen-byte stores per lane and part instead of 32 four-byte ones: 4.86 -> 4.92 ms, no gain:
-            // the cost of the [P,Q,G] output is not store issue but where the burst is waited for, see the loop head.)
+            // the cost of the [P,Q,G] output is not store issue; stores count in vmcnt on gfx950, so the barrier that waits for the
+            // next chunk's DMA also waits for the part's 1.47 GB / P store burst.)
             float* pbase = parts_out ? parts_out + ((long)p * Q + q0) * G : nullptr;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
@@ -305,7 +293,6 @@ __global__ __launch_bounds__(512, 2) void bpb_part_distance_tiled_kernel(const f
                     }
                 }
             }
-            stored = interior && parts_out != nullptr;
             ch = 0;
             ++p;
         }

@@ -53,6 +53,8 @@ TUNE = {
     'side_batch': 1,             # backward plan: weight-gradient launches issued per fork onto the side stream (0: one stream)
     'graph_side_batch': 0,       # the same for a step captured into a hipGraph (every cross-stream edge costs at replay; 0 measured best)
     's1_bigtile_branches': 2,    # branch count of the module steps that take 256-pixel tiles (3 measured 32.2 instead of 30.5 ms per step)
+    's1_1x1_region_nt1': 1,      # every 1x1 convolution inside a fork region on the 32-channel wave tile: ONE launch per exchange round
+                                 # instead of two (eval forward 7.59 -> 7.45 ms, train-mode forward 10.01 -> 9.88, profiles/r05_ab_1x1_region_tile.txt)
     's1_tstore': 1,              # 0 = no transposed forward epilogue, 2 = also with BatchNorm statistics (13 % slower there)
 }
 for _kv in filter(None, os.environ.get('BPB_TUNE', '').split(',')):      # measurement hook: BPB_TUNE=wgrad16_blocks=384,wgrad16_tpb=8
@@ -412,6 +414,10 @@ class Net:
             else:
                 mt_r, nt = 1, (2 if cout >= 64 else 1)
                 lwn = 1 if cout >= 128 else 0
+                if in_region and TUNE['s1_1x1_region_nt1']:
+                    # the up-paths of an HRNet exchange step: ONE kernel variant for all of them (32- and >= 64-channel targets
+                    # used to be two launches of 11-18 us each in every exchange step)
+                    nt, lwn = 1, 0
                 if k2 >= 256 and cout >= 1024 and wgs(2, nt, lwn) >= 512:
                     mt_r = 2
                 # 1x1 launches that stand alone (ResNet-50 layers 2-4, both directions; tools/s1_sweep.py 1x1 ->

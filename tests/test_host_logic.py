@@ -250,7 +250,8 @@ def test_standalone_1x1_convolutions_take_128_pixel_tiles_where_every_cu_still_g
     assert tile(64, 16, 8, 1024, 256, pw=True) == (0, 1) and tile(64, 16, 8, 256, 1024, pw=True) == (0, 1)
     assert tile(64, 64, 32, 64, 64, region=True, pw=True) == (0, 2) and tile(4, 16, 8, 64, 64, pw=True) == (0, 1)
     assert tile(8, 16, 8, 1024, 256) == (1, 1, 2, 32)         # batch 8: 32 workgroups of the large tile -> not used
-    assert tile(64, 16, 8, 1024, 256, region=True) == (1, 1, 2, 32)
+    # inside a fork region: the 32-channel wave tile for every 1x1 convolution (one kernel variant = one launch per exchange round)
+    assert tile(64, 16, 8, 1024, 256, region=True) == (1, 0, 1, 32)
     assert tile(64, 16, 8, 1024, 256, tuned=False) == (1, 1, 2, 32)
     assert tile(64, 16, 8, 512, 2048, tuned=False) == (2, 1, 2, 16)
 
