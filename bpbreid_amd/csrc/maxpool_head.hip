@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256) void mp_fwd_kernel(const float* __restrict__ x
             for (int k = 0; k < MP_MAXK; ++k)
                 if (k < K) {
                     const float v = mn[(long)k * HW + p] * xv;
-                    if (v > best[k] || v != v) {          // (NaN propagates like ATen's adaptive_max_pool2d)
+                    if (v > best[k] || (v != v && best[k] == best[k])) {   // NaN propagates like ATen's adaptive_max_pool2d; the FIRST NaN of
+                                                                           // this row lane keeps its position (the merge below: earliest NaN wins)
                         best[k] = v;
                         at[k] = p;
                     }

@@ -50,6 +50,7 @@ TUNE = {
     'pw_per_cu': 2,              # bpb_conv_pw: persistent workgroups per CU (~195 VGPRs: two = eight waves)
     'pw_ntc_max': 128,           # bpb_conv_pw with K = 64: widest column block of a workgroup (128: 41 KB of LDS, two workgroups per CU;
                                  # 256 = 83 KB leaves ONE per CU: 64->256 @64x32 65 instead of 58 us, profiles/r05_conv_bench_1x1_*.txt)
+    'side_stream_priority': 0,   # priority of the side stream (-1 high, 0 = the caller's, 1 low: measurement knob)
     'side_batch': 1,             # backward plan: weight-gradient launches issued per fork onto the side stream (0: one stream)
     'graph_side_batch': 0,       # the same for a step captured into a hipGraph (every cross-stream edge costs at replay; 0 measured best)
     's1_bigtile_branches': 2,    # branch count of the module steps that take 256-pixel tiles (3 measured 32.2 instead of 30.5 ms per step)
@@ -1528,10 +1529,10 @@ class Net:
             # stride-1 1x1 data gradient on dy -- the lean kernel into a compact buffer, then one zero-insertion pass over dx
             # (the general kernel ran four parity classes, three of them empty tap sets that only write zeros: 40 TFLOP/s)
             tmp = torch.empty(y.N * y.H * y.W * x.C, device=self.device, dtype=torch.float32)
-            self.keep.append(tmp)
             prob = self.s1_problem(gy, (y.N, y.H, y.W), cv.wd, tmp, cout, x.C, 1, accumulate=0, wflip=1, in_region=self._bwd_region != 0,
                                    nbranch=self._region_slots().get(self._bwd_region, 0))
             if prob is not None:
+                self.keep.append(tmp)          # (kept only when the lean problem exists: the general kernel below does not use it)
                 bwd.add(self._conv_rec(prob, 'conv_dgrad'))
                 bwd.add(self._single(nv.OP_SCATTER_S2, 'scatter_stride2', 0, 4.0 * (tmp.numel() * (2 if acc else 1) + (tmp.numel() if acc else x.buf.numel())),
                                      ints=(y.N, y.H, y.W, x.H, x.W, x.C, acc), ptrs=(tmp, gx)))
@@ -1578,7 +1579,11 @@ class Net:
     def _side_objects(self):
         if self._side is None:
             with torch.cuda.device(self.device):       # (same priority as the caller's stream: a high-priority side stream measured the same)
-                side = torch.cuda.Stream(device=self.device)
+                pr = TUNE['side_stream_priority']
+                try:
+                    side = torch.cuda.Stream(device=self.device, priority=pr) if pr else torch.cuda.Stream(device=self.device)
+                except Exception:
+                    side = torch.cuda.Stream(device=self.device)
             evs = []
             for _ in range(2):
                 h = C.c_void_p()

@@ -201,9 +201,15 @@ class BPBreID(nn.Module):
         if m.dim_reduce not in ('none', 'before_pooling', 'after_pooling', 'before_and_after_pooling'):
             raise NotImplementedError("dim_reduce=%r: 'after_pooling_with_dropout' crashes in the reference (nn.opout, "
                                       'bpbreid.py:337)' % (m.dim_reduce,))
+        if m.normalization in ('batch_norm_1d', 'batch_norm_3d'):
+            # bpbreid.py:449-456 constructs nn.BatchNorm1d / nn.BatchNorm3d and applies it to the 4-D [N*K, C, H, W] mask x feature
+            # product: the reference's own first forward raises "expected 2D or 3D input (got 4D input)" / "expected 5D input"
+            # (verified against /root/reference) -- there is no behaviour to reproduce
+            raise ValueError("normalization=%r: the reference applies this BatchNorm to a 4-D tensor and fails at its first forward "
+                             "(bpbreid.py:449-456, :463); use 'identity'" % (m.normalization,))
         if m.pooling not in ('gwap', 'gap', 'gmp') or m.normalization != 'identity':
-            # the BatchNorm normalisations of the materialised [N*K, C, H, W] product (bpbreid.py:444-456; "obsolete",
-            # default_config.py:46) are not offered
+            # 'batch_norm_2d' -- a BatchNorm2d over the materialised [N*K, C, H, W] product (bpbreid.py:451-452; marked "obsolete",
+            # default_config.py:46) -- is the one normalisation that runs in the reference and is not offered
             raise NotImplementedError("accelerated path: pooling in ('gwap', 'gap', 'gmp'), normalization='identity'; got %r / %r"
                                       % (m.pooling, m.normalization))
         self.parts_gap = m.pooling == 'gap'

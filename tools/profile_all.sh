@@ -1,33 +1,37 @@
 #!/bin/bash
-# regenerate the measurement files under profiles/<round>_* from the current build:  bash tools/profile_all.sh [r04]
-cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; P=${1:-r04}; O=$R/gpurun_out/${P}final; mkdir -p $O
+# regenerate the measurement files under profiles/<round>_* from the current build:  bash tools/profile_all.sh [r05]
+cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; P=${1:-r05}; O=$R/gpurun_out/${P}final; mkdir -p $O
+Q="--no-cpu-baseline --no-roofline --no-forward-only --no-eval --no-extra"
 # HBM traffic counters first: bench.py quotes roofline.traffic only from a file stamped with THIS build's source hash
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  (cd /tmp && timeout 600 rocprofv3 --pmc $c -d /tmp/pmc_$c -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-forward-only --no-eval --graph 0 > $O/pmc_$c.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --pmc $c -d /tmp/pmc_$c -- python $R/bench.py --steps 2 --warmup 1 $Q --graph 0 > $O/pmc_$c.log 2>&1)
 done
 python tools/pmc_hbm.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE $O/pmc_hbm.json | head -12
 cp $O/pmc_hbm.json profiles/${P}_pmc_hbm.json
+# kernel trace of the real two-stream step (the dominant kernel's in-step duration: roofline.frac_in_step) and of the one-stream plan
+# (BPB_SIDE_STREAM=0: the per-launch durations that roofline.frac = frac_alone reproduces)
+rm -rf /tmp/profk; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/profk -o $P -- python $R/bench.py --steps 10 --warmup 3 $Q --graph 0 > $O/prof_bench.json 2> $O/prof_bench.err)
+DB=$(find /tmp/profk -name "*.db" | head -1); python tools/rocprof_summary.py $DB $O/bench_kernel_stats.csv $O/bench_kernel_in_step.json | tail -1
+cp $O/bench_kernel_in_step.json profiles/${P}_bench_kernel_in_step.json
+python tools/step_trace.py $DB $O/step_trace.txt; tail -5 $O/step_trace.txt
+rm -rf /tmp/profk1; (cd /tmp && BPB_SIDE_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/profk1 -o ${P}s -- python $R/bench.py --steps 10 --warmup 3 $Q --graph 0 > $O/prof_bench_one_stream.json 2> /dev/null)
+DB=$(find /tmp/profk1 -name "*.db" | head -1); python tools/rocprof_summary.py $DB $O/bench_kernel_stats_one_stream.csv | tail -1
+# the bench line of the final build (cpu_baseline, eval, extra legs included), then the per-record timings
 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -1 $O/bench_default.json | cut -c1-200
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-eval --dump-plan-timing $O/plan_timing.json > $O/bench_20steps.json 2>/dev/null
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-eval --no-extra --dump-plan-timing $O/plan_timing.json > $O/bench_20steps.json 2>/dev/null
 python tools/plan_summary.py $O/plan_timing.json > $O/plan_summary.txt
-rm -rf /tmp/profk; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/profk -o $P -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-forward-only --no-eval --graph 0 > $O/prof_bench.json 2> $O/prof_bench.err)
-DB=$(find /tmp/profk -name "*.db" | head -1); python tools/rocprof_summary.py $DB $O/bench_kernel_stats.csv | tail -1
-python tools/step_trace.py $DB $O/step_trace.txt; tail -3 $O/step_trace.txt
 python tools/fwd_bench.py hrnet32 > $O/forward_only_hrnet32.json 2>/dev/null; tail -1 $O/forward_only_hrnet32.json | cut -c1-300
-BPB_FWD_SPATIAL=1 python tools/fwd_bench.py hrnet32 > $O/forward_only_hrnet32_with_map.json 2>/dev/null
 python tools/fwd_bench.py resnet50 > $O/forward_only_resnet50.json 2>/dev/null
 rm -rf /tmp/profe; (cd /tmp && BPB_FWD_MODES=eval timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/profe -o ${P}e -- python $R/tools/fwd_bench.py hrnet32 > /dev/null 2>&1)
 DB=$(find /tmp/profe -name "*.db" | head -1); python tools/rocprof_summary.py $DB $O/forward_eval_kernel_stats.csv | tail -1
 python tools/eval_bench.py > $O/eval_bench.json 2> $O/eval_bench.err; tail -1 $O/eval_bench.json | cut -c1-300
-python tools/conv_bench.py > $O/conv_shapes.txt 2>&1; tail -14 $O/conv_shapes.txt
-python bench.py --backbone resnet50 --steps 20 --warmup 5 --no-cpu-baseline --no-eval > $O/bench_resnet50.json 2>/dev/null; tail -1 $O/bench_resnet50.json | cut -c1-200
-python bench.py --backbone hrnet48 --parts 8 --height 384 --width 128 --steps 10 --warmup 3 --no-cpu-baseline --no-eval > $O/bench_hrnet48_k8_384.json 2>/dev/null; tail -1 $O/bench_hrnet48_k8_384.json | cut -c1-200
-timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --force-dist --steps 20 --warmup 5 --no-cpu-baseline --no-forward-only --no-eval > $O/rccl_one_rank_bench.json 2>/dev/null; tail -1 $O/rccl_one_rank_bench.json | cut -c1-120
-timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --force-dist --graph 1 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-forward-only --no-eval > $O/bench_force_dist_graph.json 2>/dev/null; tail -1 $O/bench_force_dist_graph.json | cut -c1-120
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-forward-only --no-eval --graph 1 > $O/bench_graph.json 2>/dev/null; tail -1 $O/bench_graph.json | cut -c1-120
+ONLY=1x1 python tools/conv_bench.py > $O/conv_bench_1x1.txt 2>&1; tail -8 $O/conv_bench_1x1.txt
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --force-dist --steps 20 --warmup 5 $Q --graph 0 > $O/rccl_one_rank_bench.json 2>/dev/null; tail -1 $O/rccl_one_rank_bench.json | cut -c1-120
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --force-dist --graph 1 --steps 20 --warmup 5 $Q > $O/bench_force_dist_graph.json 2>/dev/null; tail -1 $O/bench_force_dist_graph.json | cut -c1-120
+python bench.py --steps 20 --warmup 5 $Q --graph 1 > $O/bench_graph.json 2>/dev/null; tail -1 $O/bench_graph.json | cut -c1-120
 # the form the driver uses for --gpus 1, with two ranks on this one GPU (gloo): bench.py launches its own ranks
-timeout 600 python bench.py --gpus 2 --dist-backend gloo --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-forward-only --no-eval > $O/bench_selfspawn_2ranks_gloo.json 2> $O/bench_selfspawn.err; tail -1 $O/bench_selfspawn_2ranks_gloo.json | cut -c1-200
+timeout 600 python bench.py --gpus 2 --dist-backend gloo --steps 5 --warmup 2 $Q > $O/bench_selfspawn_2ranks_gloo.json 2> $O/bench_selfspawn.err; tail -1 $O/bench_selfspawn_2ranks_gloo.json | cut -c1-200
 A="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
 Bc="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAVES"
 probe() {
@@ -40,9 +44,8 @@ probe() {
   done
   grep -v "^W2026\|rocprofv3\|amdgpu.ids" /tmp/pmc_${name}_A.log | tail -1
 }
-{ echo "== conv_s1 3x3 64x32 32->32 batch 64"; probe s1_b0 "conv_s1" tools/conv_pmc.py 64 32 32 32 3 10
-  echo "== the four-branch module step (x4 grouped launch)"; probe s1_x4 "conv_s1" tools/conv_pmc.py x4 10
-  echo "== part distance Q=2048 G=20000 P=9 D=512"; probe dist "part_distance_tiled" tools/dist_pmc.py 2048 20000 9 512 2 1; } > $O/pmc_sq.txt 2>&1
-# endurance: 300 steps of the two-stream schedule with the K-split hand-overs (bench.py asserts that none timed out; the loss must stay finite)
-python bench.py --steps 300 --warmup 5 --no-cpu-baseline --no-roofline --no-forward-only --no-eval > $O/bench_300steps.json 2> $O/bench_300steps.err; tail -1 $O/bench_300steps.json | cut -c1-200
+{ echo "== the four-branch module step (x4 grouped launch of bpb_conv_s1)"; probe s1_x4 "conv_s1" tools/conv_pmc.py x4 10
+  echo "== bpb_conv_pw 64->256 at 64x32, batch 64"; probe pw "conv_pw" tools/conv_pmc.py 64 32 64 256 1 10; } > $O/pmc_sq.txt 2>&1
+# endurance: 300 steps of the two-stream schedule with the K-split hand-overs (bench.py's safety net reports a time-out; the loss must stay finite)
+python bench.py --steps 300 --warmup 5 $Q > $O/bench_300steps.json 2> $O/bench_300steps.err; tail -1 $O/bench_300steps.json | cut -c1-200
 timeout 900 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; tail -2 $O/pytest_gpu.txt
