@@ -159,17 +159,17 @@ __global__ __launch_bounds__(1024) void bpb_colsum_tall_kernel(const float* __re
 // are combined in a fixed order through LDS (deterministic).
 #define BN1D_FEATS 32
 #define BN1D_LANES 8
-__global__ __launch_bounds__(256) void bpb_bn1d_fwd_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y,
-                                                           long ldy, int R, int F, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float* __restrict__ running_mean,
-                                                           float* __restrict__ running_var, float* __restrict__ save_mean,
-                                                           float* __restrict__ save_invstd, float eps, float momentum,
-                                                           int training, int relu)
+__device__ __forceinline__ void bpb_bn1d_fwd_body(int blk, const float* __restrict__ x, long ldx, float* __restrict__ y,
+                                                  long ldy, int R, int F, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                  float* __restrict__ running_var, float* __restrict__ save_mean,
+                                                  float* __restrict__ save_invstd, float eps, float momentum,
+                                                  int training, int relu)
 {
     __shared__ double red[2][BN1D_LANES][BN1D_FEATS];
     __shared__ float stat[2][BN1D_FEATS];
     const int fl = threadIdx.x % BN1D_FEATS, rl = threadIdx.x / BN1D_FEATS;
-    const int f = blockIdx.x * BN1D_FEATS + fl;
+    const int f = blk * BN1D_FEATS + fl;
     const bool live = f < F;
     if (training) {
         double s = 0.0, q = 0.0;
@@ -226,18 +226,43 @@ __global__ __launch_bounds__(256) void bpb_bn1d_fwd_kernel(const float* __restri
     }
 }
 
+__global__ __launch_bounds__(256) void bpb_bn1d_fwd_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y,
+                                                           long ldy, int R, int F, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var, float* __restrict__ save_mean,
+                                                           float* __restrict__ save_invstd, float eps, float momentum,
+                                                           int training, int relu)
+{
+    bpb_bn1d_fwd_body((int)blockIdx.x, x, ldx, y, ldy, R, F, gamma, beta, running_mean, running_var, save_mean, save_invstd, eps, momentum,
+                      training, relu);
+}
+
+// The independent BatchNorm1d layers of one stage of the head (3 + 1 dimension-reduce layers, 4 + K BN-necks) in ONE launch: the
+// descriptors travel by value in the kernel arguments, block -> layer through the first-block prefix (13 launches of ~5 us on the
+// head's latency chain became 2, the 9 backward ones 2).
+struct BpbBn1dPack {
+    BpbBn1dDesc d[BPB_BN1D_MAX];
+};
+__global__ __launch_bounds__(256) void bpb_bn1d_fwd_multi_kernel(BpbBn1dPack pk, BpbBlkBegins bb, float eps, float momentum, int training)
+{
+    const int i = bpb_find_problem(bb, (int)blockIdx.x);
+    const BpbBn1dDesc& D = pk.d[i];
+    bpb_bn1d_fwd_body((int)blockIdx.x - D.blk_begin, D.x, D.ldx, D.y, D.ldy, D.R, D.F, D.gamma, D.beta, D.running_mean, D.running_var,
+                      D.save_mean, D.save_invstd, eps, momentum, training, D.relu);
+}
+
 // backward (training statistics): dx = g*invstd/R * (R*dy - sum dy - xhat * sum(dy*xhat)); ReLU mask from y.
-__global__ __launch_bounds__(256) void bpb_bn1d_bwd_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ x,
-                                                           long ldx, const float* __restrict__ y, long ldy,
-                                                           float* __restrict__ dx, long lddx, int R, int F,
-                                                           const float* __restrict__ gamma, const float* __restrict__ save_mean,
-                                                           const float* __restrict__ save_invstd, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, int relu, int accumulate_params)
+__device__ __forceinline__ void bpb_bn1d_bwd_body(int blk, const float* __restrict__ dy, long lddy, const float* __restrict__ x,
+                                                  long ldx, const float* __restrict__ y, long ldy,
+                                                  float* __restrict__ dx, long lddx, int R, int F,
+                                                  const float* __restrict__ gamma, const float* __restrict__ save_mean,
+                                                  const float* __restrict__ save_invstd, float* __restrict__ dgamma,
+                                                  float* __restrict__ dbeta, int relu, int accumulate_params)
 {
     __shared__ double red[2][BN1D_LANES][BN1D_FEATS];
     __shared__ float kk[2][BN1D_FEATS];
     const int fl = threadIdx.x % BN1D_FEATS, rl = threadIdx.x / BN1D_FEATS;
-    const int f = blockIdx.x * BN1D_FEATS + fl;
+    const int f = blk * BN1D_FEATS + fl;
     const bool live = f < F;
     const float mean = live ? save_mean[f] : 0.f, invstd = live ? save_invstd[f] : 0.f;
     const float g = (gamma && live) ? gamma[f] : 1.f;
@@ -289,6 +314,25 @@ __global__ __launch_bounds__(256) void bpb_bn1d_bwd_kernel(const float* __restri
         const float xh = (x[(long)r * ldx + f] - mean) * invstd;
         dx[(long)r * lddx + f] = g * invstd * (d - k1 - xh * k2);
     }
+}
+
+__global__ __launch_bounds__(256) void bpb_bn1d_bwd_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ x,
+                                                           long ldx, const float* __restrict__ y, long ldy,
+                                                           float* __restrict__ dx, long lddx, int R, int F,
+                                                           const float* __restrict__ gamma, const float* __restrict__ save_mean,
+                                                           const float* __restrict__ save_invstd, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int relu, int accumulate_params)
+{
+    bpb_bn1d_bwd_body((int)blockIdx.x, dy, lddy, x, ldx, y, ldy, dx, lddx, R, F, gamma, save_mean, save_invstd, dgamma, dbeta, relu,
+                      accumulate_params);
+}
+
+__global__ __launch_bounds__(256) void bpb_bn1d_bwd_multi_kernel(BpbBn1dPack pk, BpbBlkBegins bb)
+{
+    const int i = bpb_find_problem(bb, (int)blockIdx.x);
+    const BpbBn1dDesc& D = pk.d[i];
+    bpb_bn1d_bwd_body((int)blockIdx.x - D.blk_begin, D.dy, D.lddy, D.x, D.ldx, D.y, D.ldy, D.dx, D.lddx, D.R, D.F, D.gamma, D.save_mean,
+                      D.save_invstd, D.dgamma, D.dbeta, D.relu, D.accumulate_params);
 }
 
 extern "C" {
@@ -362,7 +406,9 @@ int bpb_gemm(const float* A, long sam, long sak, const float* B, long sbk, long 
 
 int bpb_colsum(const float* X, float* out, int M, int N, int accumulate, hipStream_t stream)
 {
-    if (M > 2048)
+    // (one thread per column walking M rows is a chain of M dependent loads: 74 us for the 320 x 512 bias gradient of the parts'
+    //  dimension-reduce layer on the head's backward chain -- sixteen row lanes from 64 rows on: ~6 us)
+    if (M > 64)
         hipLaunchKernelGGL(bpb_colsum_tall_kernel, dim3(bpb_cdiv(N, 64)), dim3(1024), 0, stream, X, out, M, N, accumulate);
     else
         hipLaunchKernelGGL(bpb_colsum_kernel, dim3(bpb_cdiv(N, 256)), dim3(256), 0, stream, X, out, M, N, accumulate);
@@ -378,6 +424,51 @@ int bpb_bn1d_fwd(const float* x, long ldx, float* y, long ldy, int R, int F, con
     BPB_REQUIRE(training || (running_mean && running_var), "bpb_bn1d_fwd: eval mode needs running statistics");
     hipLaunchKernelGGL(bpb_bn1d_fwd_kernel, dim3(bpb_cdiv(F, BN1D_FEATS)), dim3(256), 0, stream, x, ldx, y, ldy, R, F, gamma, beta,
                        running_mean, running_var, save_mean, save_invstd, eps, momentum, training, relu);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+static int bn1d_pack(const BpbBn1dDesc* h, int n, BpbBn1dPack& pk, BpbBlkBegins& bb, const char* who)
+{
+    BPB_REQUIRE(h != nullptr && n >= 1 && n <= BPB_BN1D_MAX, "%s: %d layers (1..%d)", who, n, BPB_BN1D_MAX);
+    int blk = 0;
+    for (int i = 0; i < BPB_BN1D_MAX; ++i) {
+        bb.begin[i] = 0x7fffffff;
+        if (i >= n) continue;
+        BPB_REQUIRE(h[i].R >= 1 && h[i].F >= 1 && h[i].x != nullptr, "%s: layer %d: bad sizes", who, i);
+        pk.d[i] = h[i];
+        pk.d[i].blk_begin = blk;
+        bb.begin[i] = blk;
+        blk += bpb_cdiv(h[i].F, BN1D_FEATS);
+    }
+    return blk;
+}
+
+// h_descs: HOST array of n <= BPB_BN1D_MAX layers (copied by value into the launch); bpbreid.py:335, :405 (nn.BatchNorm1d, training
+// and eval semantics of bpb_bn1d_fwd) for all of them at once
+int bpb_bn1d_fwd_multi(const BpbBn1dDesc* h_descs, int n, float eps, float momentum, int training, hipStream_t stream)
+{
+    BpbBn1dPack pk;
+    BpbBlkBegins bb;
+    const int blk = bn1d_pack(h_descs, n, pk, bb, "bpb_bn1d_fwd_multi");
+    if (blk < 0) return blk;
+    for (int i = 0; i < n; ++i)
+        BPB_REQUIRE(h_descs[i].y != nullptr && (training || (h_descs[i].running_mean && h_descs[i].running_var)),
+                    "bpb_bn1d_fwd_multi: layer %d: eval mode needs running statistics", i);
+    hipLaunchKernelGGL(bpb_bn1d_fwd_multi_kernel, dim3(blk), dim3(256), 0, stream, pk, bb, eps, momentum, training);
+    BPB_LAUNCH_OK();
+    return 0;
+}
+
+int bpb_bn1d_bwd_multi(const BpbBn1dDesc* h_descs, int n, hipStream_t stream)
+{
+    BpbBn1dPack pk;
+    BpbBlkBegins bb;
+    const int blk = bn1d_pack(h_descs, n, pk, bb, "bpb_bn1d_bwd_multi");
+    if (blk < 0) return blk;
+    for (int i = 0; i < n; ++i)
+        BPB_REQUIRE(h_descs[i].dy != nullptr && h_descs[i].dx != nullptr && h_descs[i].save_mean != nullptr, "bpb_bn1d_bwd_multi: layer %d: null operand", i);
+    hipLaunchKernelGGL(bpb_bn1d_bwd_multi_kernel, dim3(blk), dim3(256), 0, stream, pk, bb);
     BPB_LAUNCH_OK();
     return 0;
 }

@@ -161,6 +161,34 @@ class _GemmBatch:
         self.n = 0
 
 
+class _Bn1dBatch:
+    """The independent BatchNorm1d layers of one stage of the head, issued as ONE grouped launch (bpb_bn1d_fwd_multi /
+    bpb_bn1d_bwd_multi, <= 16 layers by value in the kernel arguments): add() records, flush() launches."""
+
+    def __init__(self, kind, training=True, momentum=BN_MOMENTUM):
+        self.kind, self.training, self.momentum = kind, training, momentum
+        self.descs = (nv.Bn1dDesc * nv.BN1D_MAX)()
+        self.n = 0
+
+    def add(self, **fields):
+        if self.n == nv.BN1D_MAX:
+            self.flush()
+        d = self.descs[self.n]
+        for k, v in fields.items():
+            setattr(d, k, v)
+        self.n += 1
+
+    def flush(self):
+        if not self.n:
+            return
+        if self.kind == 'fwd':
+            nv.call('bpb_bn1d_fwd_multi', self.descs, self.n, BN_EPS, float(self.momentum), 1 if self.training else 0, nv.stream())
+        else:
+            nv.call('bpb_bn1d_bwd_multi', self.descs, self.n, nv.stream())
+        self.descs = (nv.Bn1dDesc * nv.BN1D_MAX)()       # (a launch tape holds the address of the array it recorded: never reuse it)
+        self.n = 0
+
+
 class _BN1d:
     def __init__(self, bn, relu, touched, model=None):
         self.bn, self.relu, self.touched, self.model = bn, relu, touched, model
@@ -168,20 +196,19 @@ class _BN1d:
         self.save_mean = _f32(f, device=bn.weight.device)
         self.save_invstd = _f32(f, device=bn.weight.device)
 
-    def fwd(self, x_ptr, ldx, rows, y_ptr, ldy, training):
+    def fwd(self, x_ptr, ldx, rows, y_ptr, ldy, batch):
         bn = self.bn
         self._x, self._ldx, self._y, self._ldy, self._rows = x_ptr, ldx, y_ptr, ldy, rows
-        nv.call('bpb_bn1d_fwd', x_ptr, ldx, y_ptr, ldy, rows, bn.num_features, bn.weight.data_ptr(), bn.bias.data_ptr(),
-                bn.running_mean.data_ptr(), bn.running_var.data_ptr(), self.save_mean.data_ptr(),
-                self.save_invstd.data_ptr(), BN_EPS, float(self.model.bn_momentum) if self.model is not None else BN_MOMENTUM,
-                1 if training else 0, 1 if self.relu else 0, nv.stream())
+        batch.add(x=x_ptr, ldx=ldx, y=y_ptr, ldy=ldy, R=rows, F=bn.num_features, gamma=bn.weight.data_ptr(), beta=bn.bias.data_ptr(),
+                  running_mean=bn.running_mean.data_ptr(), running_var=bn.running_var.data_ptr(), save_mean=self.save_mean.data_ptr(),
+                  save_invstd=self.save_invstd.data_ptr(), relu=1 if self.relu else 0)
 
-    def bwd(self, dy_ptr, lddy, dx_ptr, lddx):
+    def bwd(self, dy_ptr, lddy, dx_ptr, lddx, batch):
         bn = self.bn
         dbeta = bn.bias.grad.data_ptr() if bn.bias.requires_grad else None
-        nv.call('bpb_bn1d_bwd', dy_ptr, lddy, self._x, self._ldx, self._y, self._ldy, dx_ptr, lddx, self._rows,
-                bn.num_features, bn.weight.data_ptr(), self.save_mean.data_ptr(), self.save_invstd.data_ptr(),
-                bn.weight.grad.data_ptr(), dbeta, 1 if self.relu else 0, 0, nv.stream())
+        batch.add(dy=dy_ptr, lddy=lddy, x=self._x, ldx=self._ldx, y=self._y, ldy=self._ldy, dx=dx_ptr, lddx=lddx, R=self._rows,
+                  F=bn.num_features, gamma=bn.weight.data_ptr(), save_mean=self.save_mean.data_ptr(), save_invstd=self.save_invstd.data_ptr(),
+                  dgamma=bn.weight.grad.data_ptr(), dbeta=dbeta, relu=1 if self.relu else 0, accumulate_params=0)
         self.touched.add(id(bn.weight))
         if dbeta is not None:
             self.touched.add(id(bn.bias))
@@ -757,12 +784,14 @@ class _ModelPlan:
             for k in range(K):
                 self.dr_p_lin[k].fwd(pp + (3 + k) * Cc * 4, J * Cc, n, self.lin_p.data_ptr() + k * D * 4, K * D, batch)
             batch.flush()
+            bns = _Bn1dBatch('fwd', training, float(m.bn_momentum))          # the four BatchNorm1d layers of this stage: one launch
             for key, row, lin_buf in stage:
                 out = f(n, D)
-                self.dr[key][1].fwd(lin_buf.data_ptr(), D, n, out.data_ptr(), D, training)
+                self.dr[key][1].fwd(lin_buf.data_ptr(), D, n, out.data_ptr(), D, bns)
                 o[key] = out
             o['p'] = f(n, K, D)
-            self.dr_p_bn.fwd(self.lin_p.data_ptr(), D, n * K, o['p'].data_ptr(), D, training)
+            self.dr_p_bn.fwd(self.lin_p.data_ptr(), D, n * K, o['p'].data_ptr(), D, bns)
+            bns.flush()
         else:                                          # the pooled rows are the embeddings (bpbreid.py:205-209 skipped)
             for key, r in (('g', 0), ('f', 1), ('b', 2)):
                 o[key] = f(n, Cc)
@@ -771,21 +800,23 @@ class _ModelPlan:
             nv.call('bpb_copy2d', pp + 3 * Cc * 4, J * Cc, o['p'].data_ptr(), K * Cc, n, K * Cc, s())
         # ---- BN-neck identity classifiers: every BatchNorm1d first, then the 4 + K (or 5) Linear layers as one grouped launch
         e = {}
+        bns = _Bn1dBatch('fwd', training, float(m.bn_momentum))
         for key, src, width in (('g', o['g'], D), ('b', o['b'], D), ('f', o['f'], D), ('c', o['p'], K * D)):
             bn, lin = self.cls[key]
             feat, sc = f(n, width), f(n, ncls)
-            bn.fwd(src.data_ptr(), width, n, feat.data_ptr(), width, training)
+            bn.fwd(src.data_ptr(), width, n, feat.data_ptr(), width, bns)
             lin.fwd(feat.data_ptr(), width, n, sc.data_ptr(), ncls, batch)
             e[key] = (feat, sc)
         bn_p, s_p = f(n, K, D), f(n, K, ncls)
         if m.shared_parts_id_classifier:
             bn, lin = self.cls_p[0]
-            bn.fwd(o['p'].data_ptr(), D, n * K, bn_p.data_ptr(), D, training)
+            bn.fwd(o['p'].data_ptr(), D, n * K, bn_p.data_ptr(), D, bns)
             lin.fwd(bn_p.data_ptr(), D, n * K, s_p.data_ptr(), ncls, batch)
         else:
             for k, (bn, lin) in enumerate(self.cls_p):
-                bn.fwd(o['p'].data_ptr() + k * D * 4, K * D, n, bn_p.data_ptr() + k * D * 4, K * D, training)
+                bn.fwd(o['p'].data_ptr() + k * D * 4, K * D, n, bn_p.data_ptr() + k * D * 4, K * D, bns)
                 lin.fwd(bn_p.data_ptr() + k * D * 4, K * D, n, s_p.data_ptr() + k * ncls * 4, K * ncls, batch)
+        bns.flush()                                      # every BN-neck of the stage in one launch, then their Linear layers in one
         batch.flush()
         self.o, self.e = o, e
         self.bn_p, self.s_p = bn_p, s_p
@@ -838,10 +869,19 @@ class _ModelPlan:
                 static.append(t)
             return t
 
+        lazy_zero = set()        # buffers that start at zero: their FIRST contribution overwrites instead of a fill + accumulate
+
+        def first(buf):
+            """accumulate flag for a contribution to `buf`: 0 for the first one into a lazily-zeroed buffer, 1 afterwards"""
+            if id(buf) in lazy_zero:
+                lazy_zero.discard(id(buf))
+                return 0
+            return 1
+
         def init_grad(ext, *shape):
             buf = f(*shape)
             if ext is None:
-                nv.call('bpb_fill', buf.data_ptr(), 0.0, buf.numel(), s())
+                lazy_zero.add(id(buf))
             else:
                 ext = ext.contiguous()
                 nv.call('bpb_scale', ext.data_ptr(), None, 1.0, buf.data_ptr(), buf.numel(), 0, s())
@@ -871,32 +911,41 @@ class _ModelPlan:
             if gs is not None:
                 gs = gs.contiguous()
                 keep.append(gs)
-                lin.bwd(gs.data_ptr(), ncls, dfeat.data_ptr(), width, 1, batch)
+                lin.bwd(gs.data_ptr(), ncls, dfeat.data_ptr(), width, first(dfeat), batch)
             pend.append((key, bn, dfeat, width))
         parts_cls = g['s_parts'] is not None or g['e_bn_parts'] is not None
         if parts_cls:
             dfeat_p = init_grad(g['e_bn_parts'], n, K, D)
             gs = g['s_parts'].contiguous() if g['s_parts'] is not None else None
             if gs is not None:
+                acc_p = first(dfeat_p)          # (the K per-part products write disjoint column blocks: one flag for all of them)
                 if m.shared_parts_id_classifier:
-                    self.cls_p[0][1].bwd(gs.data_ptr(), ncls, dfeat_p.data_ptr(), D, 1, batch)
+                    self.cls_p[0][1].bwd(gs.data_ptr(), ncls, dfeat_p.data_ptr(), D, acc_p, batch)
                 else:
                     for k, (bn, lin) in enumerate(self.cls_p):
-                        lin.bwd(gs.data_ptr() + k * ncls * 4, K * ncls, dfeat_p.data_ptr() + k * D * 4, K * D, 1, batch)
+                        lin.bwd(gs.data_ptr() + k * ncls * 4, K * ncls, dfeat_p.data_ptr() + k * D * 4, K * D, acc_p, batch)
         batch.flush()
+        bns = _Bn1dBatch('bwd')                          # the BN-necks' backward passes: one launch, then the accumulations
+        adds = []
         for key, bn, dfeat, width in pend:
             dx = f(n, width)
-            bn.bwd(dfeat.data_ptr(), width, dx.data_ptr(), width)
-            tgt = d_o['p'] if key == 'c' else d_o[key]
-            nv.call('bpb_scale', dx.data_ptr(), None, 1.0, tgt.data_ptr(), dx.numel(), 1, s())
+            bn.bwd(dfeat.data_ptr(), width, dx.data_ptr(), width, bns)
+            adds.append((dx, d_o['p'] if key == 'c' else d_o[key]))
         if parts_cls:
             dxp = f(n, K, D)
             if m.shared_parts_id_classifier:
-                self.cls_p[0][0].bwd(dfeat_p.data_ptr(), D, dxp.data_ptr(), D)
+                self.cls_p[0][0].bwd(dfeat_p.data_ptr(), D, dxp.data_ptr(), D, bns)
             else:
                 for k, (bn, lin) in enumerate(self.cls_p):
-                    bn.bwd(dfeat_p.data_ptr() + k * D * 4, K * D, dxp.data_ptr() + k * D * 4, K * D)
-            nv.call('bpb_scale', dxp.data_ptr(), None, 1.0, d_o['p'].data_ptr(), dxp.numel(), 1, s())
+                    bn.bwd(dfeat_p.data_ptr() + k * D * 4, K * D, dxp.data_ptr() + k * D * 4, K * D, bns)
+            adds.append((dxp, d_o['p']))
+        bns.flush()
+        for dx, tgt in adds:
+            nv.call('bpb_scale', dx.data_ptr(), None, 1.0, tgt.data_ptr(), dx.numel(), first(tgt), s())
+        for key in ('g', 'b', 'f', 'p'):      # (a branch whose only gradient never arrived: cannot happen with `has`, kept as a guard)
+            if d_o[key] is not None and id(d_o[key]) in lazy_zero:
+                nv.call('bpb_fill', d_o[key].data_ptr(), 0.0, d_o[key].numel(), s())
+                lazy_zero.discard(id(d_o[key]))
         # ---- dim-reduce stacks -> gradient of the pooled rows (rows of skipped branches are zero)
         gpool = self.g_pooled
         gp_ptr = gpool.data_ptr()
@@ -909,16 +958,18 @@ class _ModelPlan:
                 nv.call('bpb_copy2d', d_o['p'].data_ptr(), K * Cc, gp_ptr + 3 * Cc * 4, J * Cc, n, K * Cc, s())
         else:
             dlins = []
+            bns = _Bn1dBatch('bwd')
             for key, row in (('g', 0), ('f', 1), ('b', 2)):
                 if not has[key]:
                     continue
                 lin, bn = self.dr[key]
                 dlin = f(n, D)
-                bn.bwd(d_o[key].data_ptr(), D, dlin.data_ptr(), D)
+                bn.bwd(d_o[key].data_ptr(), D, dlin.data_ptr(), D, bns)
                 dlins.append((lin, dlin, row))
             if has['p']:
                 dlin_p = f(n, K, D)
-                self.dr_p_bn.bwd(d_o['p'].data_ptr(), D, dlin_p.data_ptr(), D)
+                self.dr_p_bn.bwd(d_o['p'].data_ptr(), D, dlin_p.data_ptr(), D, bns)
+            bns.flush()
             for lin, dlin, row in dlins:
                 lin.bwd(dlin.data_ptr(), D, gp_ptr + row * Cc * 4, J * Cc, 0, batch)
             if has['p']:

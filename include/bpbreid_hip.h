@@ -600,6 +600,27 @@ typedef struct BpbGemmProb {
 } BpbGemmProb;
 int bpb_gemm_grouped(BpbGemmProb* probs /* host, in/out */, int nprobs, float* ws, long ws_floats, long* need_out, hipStream_t stream);
 int bpb_colsum(const float* X, float* out, int M, int N, int accumulate, hipStream_t stream);
+/* one BatchNorm1d layer of a grouped launch (bpb_bn1d_fwd_multi / bpb_bn1d_bwd_multi): the fields of the single-layer entry points */
+#define BPB_BN1D_MAX 16
+typedef struct BpbBn1dDesc {
+    const float* x;            // [R][ldx] input of the layer (forward and backward)
+    float* y;                  // [R][ldy] output (forward: written; backward: the ReLU mask is read from it)
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    float* save_mean;
+    float* save_invstd;
+    const float* dy;           // backward: [R][lddy]
+    float* dx;                 // backward: [R][lddx]
+    float* dgamma;
+    float* dbeta;              // backward: optional
+    long ldx, ldy, lddy, lddx;
+    int R, F, relu, accumulate_params;
+    int blk_begin, pad_;
+} BpbBn1dDesc;
+int bpb_bn1d_fwd_multi(const BpbBn1dDesc* h_descs, int n, float eps, float momentum, int training, hipStream_t stream);
+int bpb_bn1d_bwd_multi(const BpbBn1dDesc* h_descs, int n, hipStream_t stream);
 int bpb_bn1d_fwd(const float* x, long ldx, float* y, long ldy, int R, int F, const float* gamma, const float* beta,
                  float* running_mean, float* running_var, float* save_mean, float* save_invstd, float eps, float momentum,
                  int training, int relu, hipStream_t stream);

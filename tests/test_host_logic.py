@@ -47,7 +47,8 @@ def test_ctypes_mirrors_have_the_c_layout(tmp_path):
     pairs = {'BpbConvProb': nv.ConvProb, 'BpbConvS1Prob': nv.ConvS1Prob, 'BpbConvS1wProb': nv.ConvS1wProb, 'BpbS1BnBwd': nv.S1BnBwd, 'BpbBnFinDesc': nv.BnFinDesc, 'BpbBnBwdFinDesc': nv.BnBwdFinDesc,
              'BpbWgradReduceDesc': nv.WgradReduceDesc, 'BpbWgradProb': nv.WgradProb, 'BpbPackProb': nv.PackProb, 'BpbFuseArgs': nv.FuseArgs,
              'BpbTermBwdArgs': nv.TermBwdArgs, 'BpbBilinearArgs': nv.BilinearArgs, 'BpbBilinearBwdDesc': nv.BilinearBwdDesc, 'BpbWgrad1x1Prob': nv.Wgrad1x1Prob, 'BpbGemmProb': nv.GemmProb, 'BpbBnFinalizeArgs': nv.BnFinalizeArgs,
-             'BpbBnEvalDesc': nv.BnEvalDesc, 'BpbPlanOp': nv.PlanOp, 'BpbHeadBranch': nv.HeadBranch, 'BpbS1Split': nv.S1Split}
+             'BpbBnEvalDesc': nv.BnEvalDesc, 'BpbPlanOp': nv.PlanOp, 'BpbHeadBranch': nv.HeadBranch, 'BpbS1Split': nv.S1Split, 'BpbConvPwProb': nv.ConvPwProb, 'BpbBn1dDesc': nv.Bn1dDesc,
+             'BpbTapeOp': nv.TapeOp}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "bpbreid_hip.h"', 'int main(void) {']
     for cname, cls in pairs.items():
         lines.append('printf("%s.sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
