@@ -484,8 +484,7 @@ def main():
     if multi:
         broadcast_parameters([arena['param'], arena['fbuf']])
     eng = ImagePartBasedEngine(model, optimizer=FusedAdam(model, lr=3.5e-4, weight_decay=5e-4), losses_weights=WEIGHTS,
-                               mask_filtering_training=True, distributed=multi,
-                               high_priority_stream=os.environ.get('BPB_ENGINE_STREAM_HIGH', '1') != '0')
+                               mask_filtering_training=True, distributed=multi)
     imgs, masks, pids = Cm.synth_batch(args.batch, args.height, args.width, args.parts, args.classes, seed=1234 + (0 if args.same_data else rank))
     data = {'image': imgs.to(dev), 'mask': masks.to(dev), 'pid': pids.to(dev)}      # resident in HBM before timing
     step = lambda: eng.forward_backward(data)

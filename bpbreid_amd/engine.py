@@ -47,8 +47,7 @@ class ImagePartBasedEngine:
     def __init__(self, model, optimizer=None, losses_weights=None, loss_name='part_averaged_triplet_loss', margin=0.3,
                  mask_filtering_training=False, mask_filtering_testing=True, dist_combine_strat='mean',
                  batch_size_pairwise_dist_matrix=500, test_embeddings=('bn_foreg', 'parts'), scheduler=None, use_gpu=True,
-                 process_group=None, distributed=False, writer=None, bucket_bytes=16 << 20, need_spatial_features=False,
-                 high_priority_stream=True):
+                 process_group=None, distributed=False, writer=None, bucket_bytes=16 << 20, need_spatial_features=False):
         self.model = model
         # Neither the training step nor the evaluation reads `spatial_features` (the reference engine only hands it to its
         # feature-map visualisation, part_based_engine.py:82-84): the model then runs its head on the HRNet branch outputs and
@@ -77,12 +76,6 @@ class ImagePartBasedEngine:
         # the step as one recorded launch sequence (fused_step.FusedTrainStep): no Python, no autograd, no per-call allocation between
         # the launches; configurations it does not cover take the general path below (same kernels, same results)
         self.fused_step = os.environ.get('BPB_FUSED_STEP', '1') != '0'
-        # The train step runs on a HIGH-priority stream of the engine's own, fenced against the caller's stream on both sides: the
-        # weight-gradient side stream of the backward plan stays at normal priority, so the dispatcher prefers the workgroups of the
-        # critical chain whenever both have some ready (29.65 -> 29.52 ms per step, profiles/r05_ab_main_stream_priority.txt; the
-        # device offers two levels only, so "side stream low" is not available and "side stream high" measured 29.77).
-        self.high_priority_stream = bool(high_priority_stream)
-        self._hi_stream = None
         self._fused = {}
         self.fused_reason = None             # why the last step was NOT taped (None: it was)
 
@@ -129,19 +122,6 @@ class ImagePartBasedEngine:
         return step
 
     def forward_backward(self, data):
-        dev = data['image'].device if data['image'].device.type == 'cuda' else next(self.model.parameters()).device
-        if not self.high_priority_stream or dev.type != 'cuda' or torch.cuda.is_current_stream_capturing():
-            return self._forward_backward(data)
-        if self._hi_stream is None or self._hi_stream.device != dev:
-            self._hi_stream = torch.cuda.Stream(device=dev, priority=-1)
-        cur = torch.cuda.current_stream(dev)
-        self._hi_stream.wait_stream(cur)
-        with torch.cuda.stream(self._hi_stream):
-            out = self._forward_backward(data)
-        cur.wait_stream(self._hi_stream)              # whatever the caller enqueues next (reading the loss, the next batch) is ordered
-        return out
-
-    def _forward_backward(self, data):
         imgs, target_masks, pids, _ = self.parse_data_for_train(data)
         if not self.model.training:
             self.model.train()                           # (unconditionally it walks 1000 sub-modules: 4 ms of host time per step)
