@@ -21,22 +21,28 @@ h, w, cin, cout, k = shapes[0]
 N = 64
 flops = sum(2.0 * N * h_ * w_ * k_ * k_ * ci_ * co_ for h_, w_, ci_, co_, k_ in shapes)
 net = Net(dev)
+if os.environ.get('CONV_PMC_NOPAD') == '0':    # every halo padded (LD = CK + 4): the bank-conflict counter's control
+    net.s1_nopad = False
 if os.environ.get('CONV_PMC_TILE'):
     net.force_tile = tuple(int(v) for v in os.environ['CONV_PMC_TILE'].split(','))
 if os.environ.get('CONV_PMC_CK'):
     net.force_ck = int(os.environ['CONV_PMC_CK'])
-net.fork(max(2, len(shapes)))          # inside a fork region: the tile policy of the grouped module steps
+standalone = os.environ.get('CONV_PMC_STANDALONE') == '1'      # a launch of its own (layer 1: 1x1 shapes then take bpb_conv_pw)
+if not standalone:
+    net.fork(max(2, len(shapes)))          # inside a fork region: the tile policy of the grouped module steps
 for i, (h_, w_, ci_, co_, k_) in enumerate(shapes):
-    net.set_slot(i)
+    if not standalone:
+        net.set_slot(i)
     x = Act(net, N, h_, w_, ci_)
     x.buf.normal_()
     wt = torch.randn(co_, ci_, k_, k_, device=dev) * 0.05
     wt.grad = torch.zeros_like(wt)
     net.conv(x, wt, 1, k_ // 2)
-net.set_slot(0)
-net.join(max(2, len(shapes)))
+if not standalone:
+    net.set_slot(0)
+    net.join(max(2, len(shapes)))
 net.finalize(False)
-p = net.debug_convs[0][0]
+p = (net.debug_convs or net.debug_pw)[0][0]
 ops = [i for i, m in enumerate(net.plan_train[2]) if m['label'].startswith('conv_fwd')]
 one = (nv.PlanOp * 1)(net.plan_train[0][ops[0]])
 net.run(net.plan_train)
@@ -62,5 +68,8 @@ else:
     e.record()
     torch.cuda.synchronize()
     us = s.elapsed_time(e) * 1e3 / reps
-print('%s tile mt=%d lwn=%d nt=%d CK=%d mtiles=%d ntiles=%d : %6.1f us  %5.1f TF' % (
-    type(p).__name__, p.mt_r, p.lwn, p.nt, p.CK, p.n_mtiles, p.n_ntiles, us, flops / us * 1e-6), flush=True)
+if isinstance(p, nv.ConvPwProb):
+    print('ConvPwProb NTC=%d column blocks=%d pixel groups=%d : %6.1f us  %5.1f TF' % (p.NTC, 1 << p.l_ntiles, p.n_mtiles, us, flops / us * 1e-6), flush=True)
+else:
+    print('%s tile mt=%d lwn=%d nt=%d CK=%d mtiles=%d ntiles=%d : %6.1f us  %5.1f TF' % (
+        type(p).__name__, p.mt_r, p.lwn, p.nt, p.CK, p.n_mtiles, p.n_ntiles, us, flops / us * 1e-6), flush=True)

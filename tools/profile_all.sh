@@ -45,6 +45,7 @@ probe() {
   grep -v "^W2026\|rocprofv3\|amdgpu.ids" /tmp/pmc_${name}_A.log | tail -1
 }
 { echo "== the four-branch module step (x4 grouped launch of bpb_conv_s1)"; probe s1_x4 "conv_s1" tools/conv_pmc.py x4 10
+  export CONV_PMC_STANDALONE=1      # a launch of its own: inside a fork region the 1x1 shapes stay on bpb_conv_s1
   echo "== bpb_conv_pw 64->256 at 64x32, batch 64"; probe pw "conv_pw" tools/conv_pmc.py 64 32 64 256 1 10; } > $O/pmc_sq.txt 2>&1
 # endurance: 300 steps of the two-stream schedule with the K-split hand-overs (bench.py's safety net reports a time-out; the loss must stay finite)
 python bench.py --steps 300 --warmup 5 $Q > $O/bench_300steps.json 2> $O/bench_300steps.err; tail -1 $O/bench_300steps.json | cut -c1-200
