@@ -743,22 +743,103 @@ __device__ __forceinline__ void bpb_wgrad_reduce_body(int blk, float* red, const
     }
 }
 
+// Vector form (round 5; Cout % 4 == 0 and 16-byte aligned slabs -- every slab the planner lays out): a lane owns FOUR consecutive slab
+// elements (one 16-byte load per slab: a block row is (256 >> lsl) * 16 contiguous bytes instead of (256 >> lsl) * 4), four slabs in flight
+// per lane.  Same split-lane scheme and the same fixed order per element as the scalar body; blocks cover 4x the elements.
+// profiles/r05_ab_wgrad_reduce_vec.txt: 3.2 -> 4.6 TB/s over the 28 grouped launches of the HRNet-W32 step (0.90 -> 0.63 ms).
+__device__ __forceinline__ void bpb_wgrad_reduce_body4(int blk, f32x4* red, const float* __restrict__ ws, float* __restrict__ dw,
+                                                       int nsplit, int T, int Cin, int Cin_real, int Cout, int accumulate, int lsl)
+{
+    const long total = (long)T * Cin * Cout;
+    const int leb = 8 - lsl, eb = 1 << leb, nsl = 1 << lsl;
+    const int el = threadIdx.x & (eb - 1), sl = threadIdx.x >> leb;
+    const long e = ((long)blk * eb + el) * 4;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    if (e < total) {
+        const float* __restrict__ b = ws + e;
+        int sp = sl;
+        for (; sp + 7 * nsl < nsplit; sp += 8 * nsl) {          // eight slabs in flight while a lane has that many left
+            const f32x4 v0 = *(const f32x4*)(b + (size_t)sp * total);
+            const f32x4 v1 = *(const f32x4*)(b + (size_t)(sp + nsl) * total);
+            const f32x4 v2 = *(const f32x4*)(b + (size_t)(sp + 2 * nsl) * total);
+            const f32x4 v3 = *(const f32x4*)(b + (size_t)(sp + 3 * nsl) * total);
+            const f32x4 v4 = *(const f32x4*)(b + (size_t)(sp + 4 * nsl) * total);
+            const f32x4 v5 = *(const f32x4*)(b + (size_t)(sp + 5 * nsl) * total);
+            const f32x4 v6 = *(const f32x4*)(b + (size_t)(sp + 6 * nsl) * total);
+            const f32x4 v7 = *(const f32x4*)(b + (size_t)(sp + 7 * nsl) * total);
+            s0 += v0;
+            s1 += v1;
+            s2 += v2;
+            s3 += v3;
+            s0 += v4;
+            s1 += v5;
+            s2 += v6;
+            s3 += v7;
+        }
+        for (; sp + 3 * nsl < nsplit; sp += 4 * nsl) {
+            const f32x4 v0 = *(const f32x4*)(b + (size_t)sp * total);
+            const f32x4 v1 = *(const f32x4*)(b + (size_t)(sp + nsl) * total);
+            const f32x4 v2 = *(const f32x4*)(b + (size_t)(sp + 2 * nsl) * total);
+            const f32x4 v3 = *(const f32x4*)(b + (size_t)(sp + 3 * nsl) * total);
+            s0 += v0;
+            s1 += v1;
+            s2 += v2;
+            s3 += v3;
+        }
+        for (; sp < nsplit; sp += nsl) s0 += *(const f32x4*)(b + (size_t)sp * total);
+    }
+    f32x4 s = (s0 + s1) + (s2 + s3);
+    if (lsl > 0) {
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (sl == 0) {
+            s = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < nsl; ++i) s += red[i * eb + el];
+        }
+    }
+    if (sl == 0 && e < total) {
+        const int co = (int)(e % Cout);             // co .. co + 3 share (ci, t): Cout % 4 == 0
+        const long r = e / Cout;
+        const int ci = (int)(r % Cin), t = (int)(r / Cin);
+        if (ci < Cin_real) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const size_t o = ((size_t)(co + j) * Cin_real + ci) * T + t;
+                dw[o] = accumulate ? dw[o] + s[j] : s[j];
+            }
+        }
+    }
+}
+
 static inline int bpb_wgrad_reduce_lsl(int nsplit) { return nsplit <= 4 ? 0 : nsplit <= 32 ? 2 : 4; }
+// field pad_ of a record / what the single entry point derives: lsl | 256 when the vector form applies
+static inline int bpb_wgrad_reduce_form(int nsplit, int Cout, const float* ws)
+{
+    return bpb_wgrad_reduce_lsl(nsplit) | ((Cout % 4 == 0 && ((uintptr_t)ws & 15) == 0) ? 256 : 0);
+}
+static inline int bpb_wgrad_reduce_blocks(long total, int form)
+{
+    return (int)bpb_cdiv(total, (long)(256 >> (form & 255)) << ((form & 256) ? 2 : 0));
+}
 
 __global__ __launch_bounds__(256) void bpb_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int T,
-                                                               int Cin, int Cin_real, int Cout, int accumulate, int lsl)
+                                                               int Cin, int Cin_real, int Cout, int accumulate, int form)
 {
-    __shared__ float red[256];
-    bpb_wgrad_reduce_body(blockIdx.x, red, ws, dw, nsplit, T, Cin, Cin_real, Cout, accumulate, lsl);
+    __shared__ f32x4 red[256];
+    if (form & 256) bpb_wgrad_reduce_body4(blockIdx.x, red, ws, dw, nsplit, T, Cin, Cin_real, Cout, accumulate, form & 255);
+    else bpb_wgrad_reduce_body(blockIdx.x, (float*)red, ws, dw, nsplit, T, Cin, Cin_real, Cout, accumulate, form & 255);
 }
 
 // grouped: the slab reductions of the convolutions of one module step in one launch (blk_begin prefix)
 __global__ __launch_bounds__(256) void bpb_wgrad_reduce_multi_kernel(const BpbWgradReduceDesc* __restrict__ descs, BpbBlkBegins bb)
 {
-    __shared__ float red[256];
+    __shared__ f32x4 red[256];
     const int di = bpb_find_problem(bb, (int)blockIdx.x);
     const BpbWgradReduceDesc D = descs[di];
-    bpb_wgrad_reduce_body(blockIdx.x - D.blk_begin, red, D.ws, D.dw, D.nsplit, D.T, D.Cin, D.Cin_real, D.Cout, D.accumulate, D.pad_);
+    if (D.pad_ & 256)
+        bpb_wgrad_reduce_body4(blockIdx.x - D.blk_begin, red, D.ws, D.dw, D.nsplit, D.T, D.Cin, D.Cin_real, D.Cout, D.accumulate, D.pad_ & 255);
+    else
+        bpb_wgrad_reduce_body(blockIdx.x - D.blk_begin, (float*)red, D.ws, D.dw, D.nsplit, D.T, D.Cin, D.Cin_real, D.Cout, D.accumulate, D.pad_ & 255);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -963,10 +1044,10 @@ int bpb_wgrad_reduce(const float* ws, float* dw, int nsplit, int T, int Cin, int
 {
     const long total = (long)T * Cin * Cout;
     BPB_REQUIRE(total > 0 && nsplit >= 1 && Cin_real <= Cin, "bpb_wgrad_reduce: empty problem");
-    const int lsl = bpb_wgrad_reduce_lsl(nsplit);
-    const int grid = bpb_cdiv(total, 256 >> lsl);
+    const int form = bpb_wgrad_reduce_form(nsplit, Cout, ws);
+    const int grid = bpb_wgrad_reduce_blocks(total, form);
     hipLaunchKernelGGL(bpb_wgrad_reduce_kernel, dim3(grid), dim3(256), 0, stream, ws, dw, nsplit, T, Cin, Cin_real, Cout,
-                       accumulate, lsl);
+                       accumulate, form);
     BPB_LAUNCH_OK();
     return 0;
 }
@@ -980,9 +1061,12 @@ int bpb_wgrad_reduce_multi(const BpbWgradReduceDesc* d_descs, const BpbWgradRedu
         const long total = (long)h_descs[i].T * h_descs[i].Cin * h_descs[i].Cout;
         BPB_REQUIRE(total > 0 && h_descs[i].nsplit >= 1 && h_descs[i].Cin_real <= h_descs[i].Cin && h_descs[i].blk_begin == blk,
                     "bpb_wgrad_reduce_multi: record %d", i);
-        BPB_REQUIRE(h_descs[i].pad_ == bpb_wgrad_reduce_lsl(h_descs[i].nsplit), "bpb_wgrad_reduce_multi: record %d: lsl (field pad_) must be %d",
-                    i, bpb_wgrad_reduce_lsl(h_descs[i].nsplit));
-        blk += bpb_cdiv(total, 256 >> h_descs[i].pad_);
+        // any split-lane count 1 .. 16 is valid (the planner's choice); the vector form needs aligned slabs and Cout % 4 == 0
+        const int form = bpb_wgrad_reduce_form(h_descs[i].nsplit, h_descs[i].Cout, h_descs[i].ws);
+        BPB_REQUIRE((h_descs[i].pad_ & 255) <= 4 && (h_descs[i].pad_ & ~(255 | (form & 256))) == 0,
+                    "bpb_wgrad_reduce_multi: record %d: form (field pad_ = lsl 0..4 [| 256 for 16-byte slabs with Cout %% 4 == 0]) is %d", i,
+                    h_descs[i].pad_);
+        blk += bpb_wgrad_reduce_blocks(total, h_descs[i].pad_);
     }
     BPB_REQUIRE(blk == total_blocks, "bpb_wgrad_reduce_multi: block count mismatch");
     hipLaunchKernelGGL(bpb_wgrad_reduce_multi_kernel, dim3(total_blocks), dim3(256), 0, stream, d_descs, bpb_blk_begins(h_descs, n));

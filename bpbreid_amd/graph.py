@@ -44,6 +44,8 @@ TUNE = {
     'wgrad16_blocks': 256,       # wgrad16: workgroups per problem (64 ... 384 measured: 47.1, 45.3, 42.6, 41.9, 40.2, 42.0 ms per step)
     'wgrad16_tpb': 4,
     'wgrad1x1_blocks': 512,
+    'wgrad_reduce_lsl_big': 4,   # log2 of the split lanes per block of a slab reduce over more than 32 slabs
+    'wgrad_reduce_vec': 1,       # slab reduce with 16-byte lanes (0: the 4-byte form, profiles/r05_ab_wgrad_reduce_vec.txt)
     'conv_c4_blocks': 512,       # stem forward: workgroups (each walks a contiguous range of 8 x 16-pixel tiles; two per CU)
     'wgrad_c4_blocks': 512,      # stem weight gradient: workgroups (= split-K slabs of T x 4 x Cout floats)
     'concat_blocks': 2048,       # head concatenation: 8 workgroups per CU
@@ -1307,14 +1309,14 @@ class Net:
         # split-K slabs of the weight gradients: the convolutions of one grouped launch must not share slabs and a slab lives
         # until its (grouped) reduce launch -> every convolution owns a range of one arena (288 GB of HBM: no recycling)
         if ws_requests:
-            ws = torch.empty(sum(e for e, _, _ in ws_requests), device=self.device, dtype=torch.float32)
+            ws = torch.empty(sum((e + 3) & ~3 for e, _, _ in ws_requests), device=self.device, dtype=torch.float32)
             self.keep.append(ws)
             self.ws_elems = ws.numel()
             off = 0
             for elems, prob, red in ws_requests:
                 prob.ws = ws.data_ptr() + 4 * off
                 red.ws = ws.data_ptr() + 4 * off
-                off += elems
+                off += (elems + 3) & ~3           # 16-byte aligned ranges: the slab reduce reads them with 16-byte lanes
 
     def _grad_target(self, a):
         """(buffer, accumulate flag) for a gradient contribution to tensor `a` from the node being planned.  A tensor read
@@ -1484,9 +1486,11 @@ class Net:
         rd = WgradReduceDesc()
         rd.dw = cv.weight.grad.data_ptr()
         rd.nsplit, rd.T, rd.Cin, rd.Cin_real, rd.Cout, rd.accumulate = wp.nsplit, t, x.C, cin_real, cout, 0
-        rd.pad_ = 0 if wp.nsplit <= 4 else 2 if wp.nsplit <= 32 else 4      # split lanes per block (see bpb_wgrad_reduce_body)
+        lsl = 0 if wp.nsplit <= 4 else 2 if wp.nsplit <= 32 else TUNE['wgrad_reduce_lsl_big']     # split lanes per block (see bpb_wgrad_reduce_body)
+        vec = 1 if cout % 4 == 0 and TUNE['wgrad_reduce_vec'] else 0         # 16-byte lanes (the slab ranges below are 16-byte aligned)
+        rd.pad_ = lsl | (256 * vec)
         rec_r = Rec(nv.OP_WGRAD_REDUCE_MULTI, 'wgrad_reduce', 0, 4.0 * (elems + t * cin_real * cout), desc=rd, key=('wgr',),
-                    blocks=_cdiv(t * x.C * cout, 256 >> rd.pad_))
+                    blocks=_cdiv(t * x.C * cout, (256 >> lsl) << (2 * vec)))
         rec_r.side = True
         # the slab reduce only has to run before the optimizer / the gradient exchange reads dW: the reduces of a whole fork
         # region are launched together at its end (<= 16 convolutions per launch) instead of one small launch per conv level

@@ -326,7 +326,9 @@ typedef struct BpbWgradReduceDesc { /* bpb_wgrad_reduce for one convolution: blo
     const float* ws;               // [nsplit][T][Cin][Cout]
     float* dw;                     // OIHW
     int nsplit, T, Cin, Cin_real, Cout, accumulate, blk_begin;
-    int pad_;                      // log2 of the split lanes per block: 0 (nsplit <= 4), 2 (<= 32) or 4; blocks = ceil(T*Cin*Cout / (256 >> pad_))
+    int pad_;                      // lsl | vec:  lsl = log2 of the split lanes per block: 0 (nsplit <= 4), 2 (<= 32) or 4;  vec = 256 when
+                                   // Cout % 4 == 0 and ws is 16-byte aligned (a lane owns four elements), else 0;
+                                   // blocks = ceil(T*Cin*Cout / ((256 >> lsl) * (vec ? 4 : 1)))
 } BpbWgradReduceDesc;
 
 /* bilinear (align_corners) upsample of one map into a channel slice of the concatenated map */

@@ -117,6 +117,32 @@ def test_stem_forward_kernel(r, n, hi, wi, nblk):
     assert torch.equal(y, y3)
 
 
+@pytest.mark.parametrize('accumulate', [0, 1])
+@pytest.mark.parametrize('nsplit, t, cin, cin_real, cout', [(1, 9, 32, 32, 32), (3, 9, 8, 8, 64), (7, 1, 64, 64, 256), (20, 9, 4, 3, 64), (33, 9, 32, 32, 36),
+                                                          (256, 9, 32, 32, 32), (5, 1, 12, 12, 6), (40, 9, 16, 16, 30)])
+def test_split_k_slab_reduce_scalar_and_vector_forms(nsplit, t, cin, cin_real, cout, accumulate):
+    """bpb_wgrad_reduce: dW[co][ci][t] (+)= sum_split ws[split][t][ci][co] (OIHW out of the slab layout).  16-byte aligned slabs with
+    Cout % 4 == 0 take the vector form (a lane owns four elements), anything else the scalar one: both against the fp64 sum, and the
+    SAME slabs at a 4-byte offset (scalar form) against the aligned call -- fixed summation orders, equal up to fp32 round-off."""
+    g = torch.Generator().manual_seed(nsplit * 131 + cout)
+    total = t * cin * cout
+    arena = torch.empty(nsplit * total + 8, device=DEV)
+    vals = torch.randn(nsplit, t, cin, cout, generator=g)
+    want = vals.double().sum(0)[:, :cin_real].permute(2, 1, 0).contiguous()        # [co][ci_real][t]
+    dw0 = torch.randn(cout, cin_real, t, generator=g)
+    outs = []
+    for off in (0, 1):
+        ws = arena[off:off + nsplit * total]
+        ws.copy_(vals.flatten())
+        dw = dw0.clone().to(DEV)
+        nv.call('bpb_wgrad_reduce', ws.data_ptr(), dw.data_ptr(), nsplit, t, cin, cin_real, cout, accumulate, nv.stream())
+        torch.cuda.synchronize()
+        ref = want + (dw0.double() if accumulate else 0)
+        assert rel_err(dw, ref) < 2e-6 * max(1, nsplit) ** 0.5, (off, nsplit, cout)
+        outs.append(dw.cpu())
+    assert rel_err(outs[0], outs[1].double()) < 1e-5
+
+
 @pytest.mark.parametrize('n, h, w, c', [(2, 8, 6, 8), (3, 9, 7, 64), (1, 1, 5, 4), (2, 16, 8, 256)])
 def test_zero_insertion_pass_of_the_strided_1x1_data_gradient(n, h, w, c):
     """bpb_scatter_stride2: dst at the even pixels (+)= src, zero (write mode) or untouched (accumulate mode) elsewhere; odd extents."""
