@@ -881,6 +881,28 @@ __global__ __launch_bounds__(256) void bpb_pack_weights_kernel(const BpbPackProb
         }
     }
     __syncthreads();
+    // F(2,3) packing (P.wino bit 0: wf, bit 1: wd; T == 9): 12 "taps" [column tap s][position q] with the row-transformed filters
+    //   q = 0: g0   1: (g0 + g1 + g2) / 2   2: (g0 - g1 + g2) / 2   3: g2        (g_r = W[..][r][s]; csrc/conv_s1.hip, WINO)
+    // the data-gradient side transforms the MIRRORED filter g'_r = W[..][2 - r][2 - s'] (its kernel runs with wflip = 0)
+    auto wino_val = [&](int co_l, int cil, int t12, bool mirror) {
+        const int s_ = t12 >> 2, q = t12 & 3;
+        const float* g = tile + co_l * PACK_ROW + cil * 9 + (mirror ? 2 - s_ : s_);
+        const float g0 = mirror ? g[6] : g[0], g1 = g[3], g2 = mirror ? g[0] : g[6];
+        return q == 0 ? g0 : q == 3 ? g2 : q == 1 ? 0.5f * ((g0 + g1) + g2) : 0.5f * ((g0 - g1) + g2);
+    };
+    if (P.wino & 1) {
+        const int co_l = lane >> 2, e = lane & 3, co = c0 + co_l;
+        const float sc = (P.scale && co < Cout) ? P.scale[co] : 1.f;
+        const int nq = ncp >> 2;
+        for (int pr = wave; pr < 12 * nq; pr += 4) {
+            const int t = pr / nq, ql = pr - t * nq;
+            const int cil = ql * 4 + e;
+            if (co < Cout) {
+                const float v = cil < nci ? wino_val(co_l, cil, t, false) * sc : 0.f;
+                P.wf[(((size_t)t * (Cinp >> 2) + (i0 >> 2) + ql) * Cout + co) * 4 + e] = v;
+            }
+        }
+    } else
     // ---- forward layout wf[t][ci/4][co][4]: one (tap, channel quad) = 16 co x 4 e = 64 consecutive floats
     {
         const int co_l = lane >> 2, e = lane & 3, co = c0 + co_l;
@@ -898,12 +920,13 @@ __global__ __launch_bounds__(256) void bpb_pack_weights_kernel(const BpbPackProb
     // ---- data-gradient layout wd[t][co/4][ci][4]: one (tap, output-channel quad) = ncp ci x 4 e' = 4 * ncp consecutive floats
     if (P.wd) {
         const int per = ncp * 4;
-        for (int pr = wave; pr < T * (PACK_CB / 4); pr += 4) {
+        const bool wdw = (P.wino & 2) != 0;
+        for (int pr = wave; pr < (wdw ? 12 : T) * (PACK_CB / 4); pr += 4) {
             const int t = pr >> 2, cq = pr & 3;
             for (int c = lane; c < per; c += 64) {
                 const int cil = c >> 2, e = c & 3, co_l = cq * 4 + e, co = c0 + co_l;
                 if (co < Cout) {
-                    const float v = cil < nci ? tile[co_l * PACK_ROW + cil * T + t] : 0.f;
+                    const float v = cil >= nci ? 0.f : wdw ? wino_val(co_l, cil, t, true) : tile[co_l * PACK_ROW + cil * T + t];
                     P.wd[(((size_t)t * (Cout >> 2) + (c0 >> 2) + cq) * Cinp + i0 + cil) * 4 + e] = v;
                 }
             }

@@ -45,11 +45,19 @@ __device__ unsigned long long* g_s1_trace = nullptr;
 #define S1_ABL 0
 #endif
 
-template <int NT, int MT, int R, int KG>   // KG = 8-channel k-groups per tap and pipeline stage: channel chunk CK = 8 * KG
+// WINO (3x3 stride 1, MT = 2, KG = 1): the vertical F(2,3) minimal-filtering form.  A lane owns a PAIR of output pixels (rows 2h, 2h + 1 of
+// one column): per column tap s it reads the four input rows 2h - 1 .. 2h + 2, forms d0 - d2, d1 + d2, d2 - d1, d1 - d3 and multiplies them with
+// the four row-transformed filters g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2 of that column (packed as 12 "taps" [s][position] by
+// bpb_pack_weights) into four accumulators m0 .. m3; the two output rows are m0 + m1 + m2 and m1 - m2 - m3.  48 MFMAs per 8-channel
+// chunk for 64 pixels x 32 channels instead of 72; staging, epilogue and hand-over are those of the MT = 2 kernel (sub-tile 0 = the even
+// rows, sub-tile 1 = the odd rows of the pairs).  Round-off: at the level of the direct form (tests/test_wino_cpu.py).
+template <int NT, int MT, int R, int KG, bool WINO = false>   // KG = 8-channel k-groups per tap and pipeline stage: channel chunk CK = 8 * KG
 __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob* __restrict__ probs, BpbBlkBegins bb)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int T = R * R, PAD = R / 2, CK = 8 * KG, NJ = T * KG;
+    static_assert(!WINO || (R == 3 && MT == 2 && KG == 1), "the F(2,3) form: 3x3, two output rows per lane, 8-channel chunks");
+    constexpr int T = WINO ? 12 : R * R, PAD = R / 2, CK = 8 * KG, NJ = T * KG;
+    constexpr int MTA = WINO ? 4 : MT;            // accumulator sets per wave (WINO: the four filter positions)
     S1_TR(0);
     int bid = blockIdx.x;
     const int pi = bpb_find_problem(bb, bid);
@@ -93,18 +101,33 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob
     const int NTC = (NT * 32) << lwn;            // output channels per workgroup
     const int lNTC = (NT == 1 ? 5 : 6) + lwn;
 
+    // pixel (sub-tile mt, row j of the 32x32 MFMA tile) -> tile coordinates.  WINO: j is a pair index (column fastest, then pair row,
+    // then image); sub-tile 0 holds the even rows, sub-tile 1 the odd ones
+    auto tile_pix = [&](int mt, int j, int& tw, int& th, int& ti) {
+        if constexpr (WINO) {
+            const int p = wm * 32 + j;
+            tw = p & TWm;
+            th = (((p >> lTW) & (THm >> 1)) << 1) + mt;
+            ti = p >> (lTW + lTH - 1);
+        } else {
+            const int m = (wm * MT + mt) * 32 + j;
+            tw = m & TWm;
+            th = (m >> lTW) & THm;
+            ti = m >> (lTW + lTH);
+        }
+    };
     int pixoff[MT];   // byte offset of this lane's pixel (per 32-pixel sub-tile) inside the halo tile, + the k half
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int m = (wm * MT + mt) * 32 + l31;
-        const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
+        int tw, th, ti;
+        tile_pix(mt, l31, tw, th, ti);          // (WINO: pixoff[0] = the pair's even row = halo row of input row 2h - 1)
         pixoff[mt] = (int)M24(M24(M24(ti, HH) + th * P.S, HWd) + tw * P.S, LD) * 4 + half * 16;
     }
     const int cout_l = ntile * NTC + wni * NT * 32 + l31;
 
-    f32x16 acc[MT][NT];
+    f32x16 acc[MTA][NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MTA; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -197,15 +220,102 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob
     // instructions per MFMA with a run-time tap iterator = 58 % of the peak).  The k-loop is therefore fully unrolled over the
     // taps and the k-groups of a chunk (template R, KG): the A address of (tap, pixel sub-tile) is one precomputed VGPR + an
     // immediate, the B address one running VGPR + an immediate -- per k-group 1 VALU + MT + NT ds_read_b128 for 4*MT*NT MFMAs.
+    const int bstride = 2 * NTC * 16;          // bytes of one k-group of the weight tile
+    S1_TR(1);
+    dma_issue(cbase * CK, 0);
+    S1_TR(12);                                 // (first chunk's DMA issued)
+    if constexpr (WINO) {
+        int aw[3][4];         // LDS byte offset of this lane's input pixel (column tap s, input row 2h - 1 + r), current buffer
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) aw[s_][r] = pixoff[0] + (r * HWd + s_) * LD * 4;
+#ifndef S1_WINO_TWOLVL
+#define S1_WINO_TWOLVL 0
+#endif
+        // (chunk sums first, as the direct form: 64 more registers per 32-channel sub-tile -- two instead of three waves per SIMD; a
+        //  position's chain is 3 * Cin <= 768 products against 9 * Cin of the direct form's single-level alternative)
+        constexpr bool TWOLVL = S1_WINO_TWOLVL != 0 && NT == 1;
+        for (int c = 0; c < nch; ++c) {
+            __syncthreads();
+            if (c + 1 < nch) dma_issue((cbase + c + 1) * CK, (c + 1) & 1);
+            const char* lds = (const char*)smem;
+            int bptr = (c & 1) * bufbytes + halo_reg * 16 + boff_lane;
+            f32x16 cacc[TWOLVL ? 4 : 1][NT];
+            if constexpr (TWOLVL) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) cacc[q][nt][r] = 0.f;
+            }
+            f32x4 raw[4], V[4], fb[2][NT];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) raw[r] = *(const f32x4*)(lds + aw[0][r]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) fb[0][nt] = *(const f32x4*)(lds + bptr + nt * 512);
+            V[0] = raw[0] - raw[2];
+            V[1] = raw[1] + raw[2];
+            V[2] = raw[2] - raw[1];
+            V[3] = raw[1] - raw[3];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                const int s_ = j >> 2, q = j & 3;
+                if (j + 1 < 12) {
+                    bptr += bstride;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) fb[(j + 1) & 1][nt] = *(const f32x4*)(lds + bptr + nt * 512);
+                }
+                if (q == 0 && s_ + 1 < 3) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) raw[r] = *(const f32x4*)(lds + aw[s_ + 1][r]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        if constexpr (TWOLVL) cacc[q][nt] = MFMA32(V[q][i], fb[j & 1][nt][i], cacc[q][nt]);
+                        else acc[q][nt] = MFMA32(V[q][i], fb[j & 1][nt][i], acc[q][nt]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                if (q == 3 && s_ + 1 < 3) {
+                    V[0] = raw[0] - raw[2];
+                    V[1] = raw[1] + raw[2];
+                    V[2] = raw[2] - raw[1];
+                    V[3] = raw[1] - raw[3];
+                }
+            }
+            const int delta = (c & 1) ? -bufbytes : bufbytes;
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) aw[s_][r] += delta;
+            if constexpr (TWOLVL) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[q][nt][r] += cacc[q][nt][r];
+            }
+        }
+        // output transform: rows 2h and 2h + 1 of the pairs become the two 32-pixel sub-tiles of the MT = 2 epilogue
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float m0 = acc[0][nt][r], m1 = acc[1][nt][r], m2 = acc[2][nt][r], m3 = acc[3][nt][r];
+                acc[0][nt][r] = (m0 + m1) + m2;
+                acc[1][nt][r] = (m1 - m2) - m3;
+            }
+    } else {
     int apix[T][MT];      // LDS byte offset of this lane's A fragment of tap t (k-group 0), current buffer
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) apix[t][mt] = pixoff[mt] + ((t / R) * HWd + (t % R)) * LD * 4;
-    const int bstride = 2 * NTC * 16;          // bytes of one k-group of the weight tile
-    S1_TR(1);
-    dma_issue(cbase * CK, 0);
-    S1_TR(12);                                 // (first chunk's DMA issued)
     for (int c = 0; c < nch; ++c) {
         if (!(S1_ABL & 2) || c == 0) __syncthreads();   // chunk c has landed (the barrier drains vmcnt) and the other buffer is free again
         if (c == 0) S1_TR(2);
@@ -270,6 +380,7 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob
                 for (int r = 0; r < 16; ++r)
                     if (!(S1_ABL & 8) || c + 1 == nch) acc[mt][nt][r] += NA == 2 ? cacc[0][mt][nt][r] + cacc[NA - 1][mt][nt][r] : cacc[0][mt][nt][r];
     }
+    }   // (!WINO)
 
     S1_TR(3);
     if (P.split) {
@@ -477,8 +588,8 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob
             // tile width >= 4: the four rows (r & 3) of a register quad are four consecutive pixels of one image row
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
-                const int m = (wm * MT + mt) * 32 + 8 * rq + 4 * half;
-                const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
+                int tw, th, ti;
+                tile_pix(mt, 8 * rq + 4 * half, tw, th, ti);
                 const int n = n0 + ti, a = a0 + th, b = b0 + tw;
                 const bool pq = (n < P.N) && (a < P.H);
                 const unsigned qoff = M24(M24(M24(n, P.H) + a, P.W) + b, pstride) + (unsigned)(cout_l * 4);
@@ -488,8 +599,8 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int tw = m & TWm, th = (m >> lTW) & THm, ti = m >> (lTW + lTH);
+                int tw, th, ti;
+                tile_pix(mt, (r & 3) + 8 * (r >> 2) + 4 * half, tw, th, ti);
                 const int n = n0 + ti, a = a0 + th, b = b0 + tw;
                 const bool pv = (n < P.N) && (a < P.H) && (b < P.W);
                 offs[r] = pv ? M24(M24(M24(n, P.H) + a, P.W) + b, pstride) + (unsigned)(cout_l * 4) : PIX_OOB;
@@ -594,7 +705,7 @@ static int conv_s1_lds_bytes(const BpbConvS1Prob& p)
 {
     const int npix = (1 << p.lTI) * p.HH * p.HW;
     const int halo_reg = (npix * (p.LD / 4) + 3) & ~3;
-    const int nB = p.R * p.R * (p.CK / 4) * ((p.nt * 32) << p.lwn);
+    const int nB = (p.wino ? 12 : p.R * p.R) * (p.CK / 4) * ((p.nt * 32) << p.lwn);
     const int l = 2 * (halo_reg + nB) * 16;
     return l < 8192 ? 8192 : l;          // (the BatchNorm partial scratch of the epilogue aliases one buffer: <= 4 KiB)
 }
@@ -619,6 +730,7 @@ int bpb_conv_s1_init(void)
 #define BPB_ATTR_K(NT, MT, RR) BPB_ATTR((bpb_conv_s1_kernel<NT, MT, RR, 1>)) BPB_ATTR((bpb_conv_s1_kernel<NT, MT, RR, 2>)) BPB_ATTR((bpb_conv_s1_kernel<NT, MT, RR, 4>))
     BPB_ATTR_K(1, 1, 3) BPB_ATTR_K(1, 2, 3) BPB_ATTR_K(2, 1, 3) BPB_ATTR_K(2, 2, 3)
     BPB_ATTR_K(1, 1, 1) BPB_ATTR_K(1, 2, 1) BPB_ATTR_K(2, 1, 1) BPB_ATTR_K(2, 2, 1)
+    BPB_ATTR((bpb_conv_s1_kernel<1, 2, 3, 1, true>)) BPB_ATTR((bpb_conv_s1_kernel<2, 2, 3, 1, true>))
 #undef BPB_ATTR_K
 #undef BPB_ATTR
     return 0;
@@ -631,11 +743,14 @@ int bpb_conv_s1(const BpbConvS1Prob* d_probs, const BpbConvS1Prob* h_probs, int 
 {
     BPB_REQUIRE(nprobs >= 1 && nprobs <= 16, "bpb_conv_s1: nprobs=%d out of range", nprobs);
     int nblk = 0, lds = 0;
-    const int nt = h_probs[0].nt, mt = h_probs[0].mt_r, R = h_probs[0].R, ck = h_probs[0].CK;
+    const int nt = h_probs[0].nt, mt = h_probs[0].mt_r, R = h_probs[0].R, ck = h_probs[0].CK, wino = h_probs[0].wino;
     BPB_REQUIRE((nt == 1 || nt == 2) && (mt == 1 || mt == 2) && (R == 1 || R == 3), "bpb_conv_s1: variant nt=%d mt=%d R=%d", nt, mt, R);
     for (int i = 0; i < nprobs; ++i) {
         const BpbConvS1Prob& p = h_probs[i];
-        BPB_REQUIRE(p.nt == nt && p.mt_r == mt && p.R == R && p.CK == ck, "bpb_conv_s1: mixed kernel variants in one group");
+        BPB_REQUIRE(p.nt == nt && p.mt_r == mt && p.R == R && p.CK == ck && p.wino == wino, "bpb_conv_s1: mixed kernel variants in one group");
+        BPB_REQUIRE(p.wino == 0 || (p.wino == 1 && R == 3 && mt == 2 && ck == 8 && p.S == 1 && p.wflip == 0 && p.lTH >= 1 && p.tstore == 0),
+                    "bpb_conv_s1: the F(2,3) form is for 3x3 stride-1 problems with two-row wave tiles, 8-channel chunks and its own weight packing "
+                    "(mt=%d CK=%d S=%d wflip=%d lTH=%d)", mt, ck, p.S, p.wflip, p.lTH);
         BPB_REQUIRE(p.Cin % 8 == 0 && p.Cout % 4 == 0, "bpb_conv_s1: Cin=%d must be a multiple of 8, Cout=%d of 4", p.Cin, p.Cout);
         BPB_REQUIRE((p.CK == 8 || p.CK == 16 || p.CK == 32) && p.Cin % p.CK == 0 && (p.LD == p.CK + 4 || p.LD == p.CK),
                     "bpb_conv_s1: bad channel chunk CK=%d (LD=%d) for Cin=%d", p.CK, p.LD, p.Cin);
@@ -666,7 +781,7 @@ int bpb_conv_s1(const BpbConvS1Prob* d_probs, const BpbConvS1Prob* h_probs, int 
                     "bpb_conv_s1: a K split needs an even number of channel chunks (Cin=%d, CK=%d) and < 2 GiB of hand-over space", p.Cin, p.CK);
         const int npix = (1 << p.lTI) * p.HH * p.HW;
         const int halo_pad = (npix * (p.LD / 4) + 255) & ~255;
-        const int b_pad = (R * R * (p.CK / 4) * ((nt * 32) << p.lwn) + 255) & ~255;
+        const int b_pad = ((wino ? 12 : R * R) * (p.CK / 4) * ((nt * 32) << p.lwn) + 255) & ~255;
         BPB_REQUIRE(halo_pad <= 12 * 256 && b_pad <= 12 * 256, "bpb_conv_s1: more than 12 DMA pieces per thread (halo %d, weights %d slots)",
                     halo_pad, b_pad);
         nblk += p.n_mtiles * p.n_ntiles * (p.split ? 2 : 1);
@@ -682,7 +797,9 @@ int bpb_conv_s1(const BpbConvS1Prob* d_probs, const BpbConvS1Prob* h_probs, int 
     do { if (ck == 8) { BPB_S1_LAUNCH(NT, MT, RR, 1); } else if (ck == 16) { BPB_S1_LAUNCH(NT, MT, RR, 2); } else { BPB_S1_LAUNCH(NT, MT, RR, 4); } } while (0)
 #define BPB_S1_R(NT, MT) \
     do { if (R == 3) { BPB_S1_K(NT, MT, 3); } else { BPB_S1_K(NT, MT, 1); } } while (0)
-    if (nt == 1 && mt == 1) BPB_S1_R(1, 1);
+    if (wino && nt == 1) hipLaunchKernelGGL((bpb_conv_s1_kernel<1, 2, 3, 1, true>), dim3(nblk), dim3(256), lds, stream, d_probs, bb);
+    else if (wino) hipLaunchKernelGGL((bpb_conv_s1_kernel<2, 2, 3, 1, true>), dim3(nblk), dim3(256), lds, stream, d_probs, bb);
+    else if (nt == 1 && mt == 1) BPB_S1_R(1, 1);
     else if (nt == 1) BPB_S1_R(1, 2);
     else if (mt == 1) BPB_S1_R(2, 1);
     else BPB_S1_R(2, 2);

@@ -45,6 +45,7 @@ TUNE = {
     'wgrad16_tpb': 4,
     'wgrad1x1_blocks': 512,
     'wgrad_reduce_lsl_big': 4,   # log2 of the split lanes per block of a slab reduce over more than 32 slabs
+    'wino_ld8': 1,               # F(2,3) problems stage their halo unpadded where that buys the third workgroup per CU
     'wgrad_reduce_vec': 1,       # slab reduce with 16-byte lanes (0: the 4-byte form, profiles/r05_ab_wgrad_reduce_vec.txt)
     'conv_c4_blocks': 512,       # stem forward: workgroups (each walks a contiguous range of 8 x 16-pixel tiles; two per CU)
     'wgrad_c4_blocks': 512,      # stem weight gradient: workgroups (= split-K slabs of T x 4 x Cout floats)
@@ -234,6 +235,10 @@ class Net:
         self.eval_residual_epilogue = True   # eval plan: residual adds in the conv epilogue
         self.xcd_map = True            # XCD-aware block -> tile maps of conv_s1 / conv_s1w / conv_pw / wgrad16
         self.s1_nopad = True           # the halo of a problem whose padding alone costs the launch a workgroup per CU is staged unpadded
+        # 3x3 stride-1 convolutions, forward and data gradient, in the vertical F(2,3) minimal-filtering form (csrc/conv_s1.hip, WINO): 48
+        # instead of 72 MFMAs per chunk -- 29.3 -> 27.3 ms per step, round-off 1.7-3.3x the direct form's (tools/wino_err.py,
+        # profiles/r05_ab_f23_*); BPB_WINO=0: the direct form everywhere
+        self.use_wino = os.environ.get('BPB_WINO', '1') == '1'
         self.s1_stride2 = True         # stride-2 forward convolutions on the lean kernel
         self.multi_concat_enabled = True     # the HRNet head concatenation as one launch
         self.defer_reduce = True       # the slab reduces of a fork region launched together at its end
@@ -367,7 +372,7 @@ class Net:
 
     # ---- tile / chunk selection ---------------------------------------------------------------------------------
     def s1_problem(self, x_buf, x_dims, w_packed, y_buf, cin, cout, r, bias=None, stats=None, accumulate=0, wflip=0, relu=0,
-                   in_region=True, stride=1, nbranch=0):
+                   in_region=True, stride=1, nbranch=0, wino_ok=False):
         """Fill one ConvS1Prob (csrc/conv_s1.hip): y[N,H,W,cout] = conv_rxr(x[N,Hi,Wi,cin]), padding r // 2, stride 1 or 2;
         x_dims = (N, Hi, Wi)."""
         n, hi, wi = x_dims
@@ -440,7 +445,18 @@ class Net:
         if getattr(self, 'force_ck', None) and cin % self.force_ck == 0:
             cks = [self.force_ck]
         ck = None
-        for mt_r, nt, lwn in ([(mt_r, nt, lwn)] if forced is not None else [(mt_r, nt, lwn), (1, nt, lwn), (1, 1, lwn), (1, 1, 0)]):
+        # F(2,3) form (csrc/conv_s1.hip, WINO): a wave owns 32 vertical pixel pairs (64 pixels) x 32 * nt channels, 8-channel chunks, 12 taps
+        # (maps below 8x4 = 32 pixels: no MFMAs to save, and their BatchNorm populations are the most sensitive to round-off)
+        wino = bool(wino_ok and r == 3 and stride == 1 and forced is None and getattr(self, 'force_ck', None) in (None, 8) and h >= 2 and h * w >= 32)
+        tries = [(mt_r, nt, lwn)] if forced is not None else [(mt_r, nt, lwn), (1, nt, lwn), (1, 1, lwn), (1, 1, 0)]
+        if wino:
+            nt_w = 1 if (in_region or cout < 64 or wgs(2, 2, 0) < 512) else 2
+            tries = [('w', nt_w, 0)] + tries
+        for mt_r, nt, lwn in tries:
+            is_w = mt_r == 'w'
+            if is_w:
+                mt_r = 2
+            t = 12 if is_w else r * r
             ntc = (32 * nt) << lwn
             pixels = (4 >> lwn) * mt_r * 32
             ti, th, tw = choose_tile(n, h, w, pixels)
@@ -450,7 +466,9 @@ class Net:
                 halo_slots, w_slots = ti * hh * hw * ((ck_ + 4) // 4), t * (ck_ // 4) * ntc
                 halo, wts = pad256(halo_slots), pad256(w_slots)          # DMA pieces of 256 x 16 B
                 return halo, wts, max(8192, 2 * ((halo_slots + 3) // 4 * 4 + w_slots) * 16)     # LDS: regions packed, two buffers
-            ok = [c_ for c_ in cks if sizes(c_)[0] <= 12 * 256 and sizes(c_)[1] <= 12 * 256]   # <= 12 DMA pieces per thread
+            ok = [c_ for c_ in ((8,) if is_w else cks) if sizes(c_)[0] <= 12 * 256 and sizes(c_)[1] <= 12 * 256]   # <= 12 DMA pieces per thread
+            if is_w and th < 2:
+                ok = []
             # (the 128-pixel 1x1 tiles above: 32-channel chunks at two workgroups per CU beat 16-channel chunks at three)
             limits = (79, 160) if (want_ck32 and forced is None and (mt_r, r) == (2, 1)) else (TUNE['s1_lds_kb'], 53, 79, 160)
             for limit_kb in limits:    # >= 3, 3, 2, 1 workgroups per CU
@@ -462,7 +480,10 @@ class Net:
                 break
         if ck is None:
             return None          # tiny maps (a 2x1 map has a 6x larger halo than interior): the general kernel takes it
+        t = r * r
         p = ConvS1Prob()
+        p.wino = 1 if is_w else 0
+        tw_taps = 12 if is_w else t
         p.x, p.w, p.y = x_buf.data_ptr(), w_packed.data_ptr(), y_buf.data_ptr()
         p.bias = bias.data_ptr() if bias is not None else None
         p.stats = None
@@ -476,15 +497,17 @@ class Net:
         # (the 8x4 maps of the deepest HRNet branch: four whole images per tile, 240 halo pixels -> 41.5 KB), the launch would run
         # three instead of four workgroups per CU (tools/s1_trace.py) -- that problem stages its halo unpadded.
         quarter = 160 * 1024 // 4
-        lds_of = lambda ld_: 2 * ((ti * hh * hw * (ld_ // 4) + 3) // 4 * 4 + t * (ck // 4) * ntc) * 16
+        lds_of = lambda ld_: 2 * ((ti * hh * hw * (ld_ // 4) + 3) // 4 * 4 + tw_taps * (ck // 4) * ntc) * 16
         if lds_of(ck + 4) > quarter >= lds_of(ck) and self.s1_nopad:
             p.LD = ck
+        if is_w and TUNE['wino_ld8'] and lds_of(ck + 4) > 53 * 1024 >= lds_of(ck):
+            p.LD = ck                 # the F(2,3) tiles (256 pixels): unpadded they fit three to a CU
         p.tiles_a, p.tiles_b = _cdiv(h, th), _cdiv(w, tw)
         p.n_mtiles = _cdiv(n, ti) * p.tiles_a * p.tiles_b
         p.n_ntiles = _cdiv(cout, ntc)
         p.blk_begin = 0
         p.lwn, p.mt_r, p.nt = lwn, mt_r, nt
-        p.accumulate, p.relu, p.wflip = accumulate, relu, wflip
+        p.accumulate, p.relu, p.wflip = accumulate, relu, (0 if is_w else wflip)      # (the F(2,3) packing of a data gradient is mirrored already)
         p.x_bytes, p.w_bytes, p.y_bytes = x_buf.numel() * 4, w_packed.numel() * 4, y_buf.numel() * 4
         p.magic_spp, p.magic_hw, p.magic_hh = magic(p.LD // 4), magic(hw), magic(hh)
         p.magic_nt, p.magic_tb, p.magic_ta = magic(p.n_ntiles), magic(p.tiles_b), magic(p.tiles_a)
@@ -691,8 +714,8 @@ class Net:
                        4.0 * prob.P * (prob.Cin + prob.Cout), desc=prob, key=('pw', prob.Cin == 64), blocks=prob.n_mtiles << prob.l_ntiles,
                        work=float(prob.Cin * (prob.NTC // 32)))
         if isinstance(prob, ConvS1Prob):
-            kind, key = nv.OP_CONV_S1, ('s1', prob.nt, prob.mt_r, prob.R, prob.CK)
-            variant = 'bpb_conv_s1_kernel<%d,%d,%d,%d>' % (prob.nt, prob.mt_r, prob.R, prob.CK // 8)
+            kind, key = nv.OP_CONV_S1, ('s1', prob.nt, prob.mt_r, prob.R, prob.CK, prob.wino)
+            variant = 'bpb_conv_s1_kernel<%d,%d,%d,%d%s>' % (prob.nt, prob.mt_r, prob.R, prob.CK // 8, ',F(2,3)' if prob.wino else '')
             npix, taps, cin_in = prob.N * prob.H * prob.W, prob.R * prob.R, prob.N * prob.H * prob.W * prob.Cin
             blocks = prob.n_mtiles * prob.n_ntiles
         else:
@@ -717,8 +740,13 @@ class Net:
             cout, cin_real, r, s = cv.weight.shape
             cin_pad = 4 if cin_real == 3 else cin_real
             t = r * s
-            cv.wf = torch.empty(t * cin_pad * cout, device=dev, dtype=torch.float32)
-            cv.wd = torch.empty(t * cin_pad * cout, device=dev, dtype=torch.float32) if (train_backward and cv.x.needs_grad) else None
+            # the F(2,3) form of a 3x3 stride-1 convolution reads a 12-tap packing (4 row-transformed filters per column tap): the buffers
+            # are sized for it; whether a side uses it is known once its problem has been planned (cv.wino_f / cv.wino_d, set below)
+            cv.wino_ok = bool(self.use_wino and self.use_s1 and r == 3 and s == 3 and cv.stride == 1 and cv.pad == 1 and cin_pad % 8 == 0 and cout % 8 == 0)
+            cv.wino_f = cv.wino_d = False
+            t_alloc = 12 if cv.wino_ok else t
+            cv.wf = torch.empty(t_alloc * cin_pad * cout, device=dev, dtype=torch.float32)
+            cv.wd = torch.empty(t_alloc * cin_pad * cout, device=dev, dtype=torch.float32) if (train_backward and cv.x.needs_grad) else None
             pk = packs[k]
             pk.w, pk.wf = cv.weight.data_ptr(), cv.wf.data_ptr()
             pk.wd = cv.wd.data_ptr() if cv.wd is not None else None
@@ -735,11 +763,13 @@ class Net:
             assert cout % 4 == 0 or cv.wd is None, 'bpb_pack_weights: the data-gradient packing needs Cout % 4 == 0'
             blk += _cdiv(cout, 16) * _cdiv(cin_pad, pk.IB)
         pack_eval_rec = None
+        dpacks = dpacks_eval = None
         if self.convs:
             dpacks = self._dev_struct(packs)
+            dpacks_eval = self._dev_struct(packs_eval)
             self.fwd_train.add(self._single(nv.OP_PACK, 'pack_weights', ints=(len(self.convs), blk), ptrs=(dpacks,)))
             # (the eval plan packs after the batched eval-mode affine: its weights depend on the BatchNorm scales)
-            pack_eval_rec = self._single(nv.OP_PACK, 'pack_weights', ints=(len(self.convs), blk), ptrs=(self._dev_struct(packs_eval),))
+            pack_eval_rec = self._single(nv.OP_PACK, 'pack_weights', ints=(len(self.convs), blk), ptrs=(dpacks_eval,))
         # eval plan: a conv whose only consumer is `out = relu(bn(conv))` writes `out` itself (folded BN + ReLU epilogue)
         eval_sink, eval_skip = {}, set()
         if self.fold_eval_bn:
@@ -802,7 +832,9 @@ class Net:
                     stats.append(c4_stats)
                 elif self.use_s1 and cv.is_s1_fwd and (cv.stride == 1 or self.s1_stride2):
                     prob = self.s1_problem(x.buf, (x.N, x.H, x.W), cv.wf, y.buf, x.C, y.C, cv.R, bias=cv.bias, stats=stats,
-                                           in_region=region != 0, stride=cv.stride, nbranch=self._region_slots().get(region, 0))
+                                           in_region=region != 0, stride=cv.stride, nbranch=self._region_slots().get(region, 0),
+                                           wino_ok=cv.wino_ok)
+                    cv.wino_f = bool(prob is not None and isinstance(prob, ConvS1Prob) and prob.wino)
                 if prob is None and not c4:
                     prob = self.conv_problem(x.buf, (x.N, x.H, x.W), cv.wf, y.buf, (y.H, y.W), y.H, y.W, (1, 1, 0, 0),
                                              cv.stride, (-cv.pad, -cv.pad), (cv.R, cv.S, 0, 1, 0, 1, 0, cv.S, 1), x.C, y.C,
@@ -947,6 +979,13 @@ class Net:
             self.fwd_eval.insert(eval_affine_at, pack_eval_rec)
         if train_backward:
             self._emit_backward()
+        if dpacks is not None and any(cv.wino_f or cv.wino_d for cv in self.convs):
+            # which side of which convolution reads the F(2,3) packing is known now: complete the packing descriptors on the device
+            for k, cv in enumerate(self.convs):
+                packs[k].wino = (1 if cv.wino_f else 0) | (2 if cv.wino_d else 0)
+                packs_eval[k].wino = 1 if cv.wino_f else 0
+            for dev_, host_ in ((dpacks, packs), (dpacks_eval, packs_eval)):
+                dev_.copy_(torch.frombuffer(bytearray(C.string_at(C.addressof(host_), C.sizeof(host_))), dtype=torch.uint8))
         self.plan_groups = {}      # name -> list of groups (lists of Rec) behind the frozen launches: introspection / tests
         self.plan_train = self._freeze(self.fwd_train, 'train')
         self.plan_eval = self._freeze(self.fwd_eval, 'eval')
@@ -1512,7 +1551,9 @@ class Net:
         if self.use_s1 and cv.is_s1:
             # stride-1 'same' convolution: dx = conv(dy, W^T mirrored) -- the same lean kernel with the dgrad packing
             prob = self.s1_problem(gy, (y.N, y.H, y.W), cv.wd, gx, cout, x.C, cv.R, accumulate=acc, wflip=1,
-                                   in_region=self._bwd_region != 0, nbranch=self._region_slots().get(self._bwd_region, 0))
+                                   in_region=self._bwd_region != 0, nbranch=self._region_slots().get(self._bwd_region, 0),
+                                   wino_ok=cv.wino_ok)
+            cv.wino_d = bool(prob is not None and isinstance(prob, ConvS1Prob) and prob.wino)
             if prob is not None:
                 rec = self._conv_rec(prob, 'conv_dgrad')
                 bwd.add(rec)

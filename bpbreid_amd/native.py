@@ -41,7 +41,7 @@ class ConvS1Prob(C.Structure):
             'N', 'H', 'W', 'Cin', 'Cout', 'R', 'lTI', 'lTH', 'lTW', 'HH', 'HW', 'CK', 'LD', 'tiles_a', 'tiles_b', 'n_mtiles',
             'n_ntiles', 'blk_begin', 'lwn', 'mt_r', 'nt', 'accumulate', 'relu', 'wflip')] + [
         (n, C.c_uint) for n in ('x_bytes', 'w_bytes', 'y_bytes', 'magic_spp', 'magic_hw', 'magic_hh', 'magic_nt', 'magic_tb',
-                                'magic_ta')] + [(n, C.c_int) for n in ('S', 'Hi', 'Wi', 'xr', 'tstore')]
+                                'magic_ta')] + [(n, C.c_int) for n in ('S', 'Hi', 'Wi', 'xr', 'tstore', 'wino')]
 
 
 class ConvS1wProb(C.Structure):
@@ -108,7 +108,7 @@ BN1D_MAX = 16
 
 class PackProb(C.Structure):
     _fields_ = [('w', c_fp), ('wf', c_fp), ('wd', c_fp), ('Cout', C.c_int), ('Cin', C.c_int), ('Cin_pad', C.c_int),
-                ('T', C.c_int), ('blk_begin', C.c_int), ('IB', C.c_int), ('scale', c_fp)]
+                ('T', C.c_int), ('blk_begin', C.c_int), ('IB', C.c_int), ('scale', c_fp), ('wino', C.c_int), ('pad_', C.c_int)]
 
 
 class FuseArgs(C.Structure):

@@ -139,6 +139,9 @@ typedef struct BpbConvS1Prob {
     int Hi, Wi;             // input extent (= H, W for stride 1)
     int xr;                 // 1: XCD-aware block -> tile map (block b runs on XCD b % 8: every XCD walks a contiguous range of tiles)
     int tstore;             // 1: epilogue through an LDS transpose, 16-byte stores (plain forward problems of single-tile waves)
+    int wino;               // 1: vertical F(2,3) form (R = 3, S = 1, mt_r = 2, CK = 8, wflip = 0): w is the 12-tap packing
+                            // [column tap s][position 0..3][Cin/4][Cout][4] of bpb_pack_weights (BpbPackProb.wino), 48 instead of 72 MFMAs
+                            // per chunk and wave; the pairs of a wave tile are rows (2h, 2h + 1): lTH >= 1
 } BpbConvS1Prob;
 
 /* Pointwise (1x1, stride 1) convolution as a plain [P pixels x Cin] . [Cin x Cout] GEMM on NHWC tensors (csrc/conv_pw.hip):
@@ -236,6 +239,8 @@ typedef struct BpbPackProb {
     int blk_begin;
     int IB;               // input channels per workgroup tile (multiple of 4, IB * T <= 196): blocks = ceil(Cout / 16) * ceil(Cin_pad / IB)
     const float* scale;   // optional [Cout]: wf is multiplied by scale[co] (eval mode: BatchNorm folded into the weights)
+    int wino;             // 3x3 filters (T == 9) only: bit 0 -> wf, bit 1 -> wd in the 12-tap F(2,3) packing [s][position][..] of BpbConvS1Prob.wino
+    int pad_;
 } BpbPackProb;
 
 /* one BatchNorm of a batched eval-mode affine launch (bpb_bn_eval_affine_batched): scale = gamma / sqrt(rv + eps),

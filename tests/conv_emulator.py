@@ -31,14 +31,55 @@ def pack_dgrad(w, cin_pad):
     return out.reshape(-1)
 
 
-def run_pack(w, cin_pad, ib, scale=None, dgrad=True):
+def _wino_rows(g0, g1, g2):
+    """row-transformed filters of the vertical F(2,3) form (csrc/conv_s1.hip, WINO): positions 0..3"""
+    return [g0, 0.5 * ((g0 + g1) + g2), 0.5 * ((g0 - g1) + g2), g2]
+
+
+def pack_fwd_wino(w, cin_pad):
+    """wf[s * 4 + q][ci/4][co][4]: the 12-tap F(2,3) packing of a 3x3 filter (BpbPackProb.wino bit 0)."""
+    cout, cin, r, s = w.shape
+    assert (r, s) == (3, 3)
+    out = np.zeros((12, cin_pad // 4, cout, 4), dtype=w.dtype)
+    for sc in range(3):
+        u = _wino_rows(w[:, :, 0, sc], w[:, :, 1, sc], w[:, :, 2, sc])          # [co][ci] each
+        for q in range(4):
+            for ci in range(cin):
+                out[sc * 4 + q, ci // 4, :, ci % 4] = u[q][:, ci]
+    return out.reshape(-1)
+
+
+def pack_dgrad_wino(w, cin_pad):
+    """wd[s' * 4 + q][co/4][ci][4]: the same transform of the MIRRORED filter g'[r'][s'] = W[2 - r'][2 - s'] (bit 1; the kernel
+    then runs with wflip = 0)."""
+    cout, cin, r, s = w.shape
+    assert (r, s) == (3, 3)
+    out = np.zeros((12, cout // 4, cin_pad, 4), dtype=w.dtype)
+    for sc in range(3):
+        u = _wino_rows(w[:, :, 2, 2 - sc], w[:, :, 1, 2 - sc], w[:, :, 0, 2 - sc])
+        for q in range(4):
+            for co in range(cout):
+                out[sc * 4 + q, co // 4, :cin, co % 4] = u[q][co, :]
+    return out.reshape(-1)
+
+
+def run_pack(w, cin_pad, ib, scale=None, dgrad=True, wino=0):
     """bpb_pack_weights_kernel's workgroup loop (16 output channels x `ib` input channels x all taps per tile, csrc/conv_igemm.hip):
     returns (wf, wd, number of workgroups); every packed element must be written exactly once."""
     cout, cin, r, s = w.shape
     t = r * s
     wflat = w.reshape(-1)
-    wf = np.full(t * cin_pad * cout, np.nan, dtype=w.dtype)
-    wd = np.full(t * cout * cin_pad, np.nan, dtype=w.dtype) if dgrad else None
+    tf, td = (12 if wino & 1 else t), (12 if wino & 2 else t)          # F(2,3) packing: 12 taps [s][position]
+    wf = np.full(tf * cin_pad * cout, np.nan, dtype=w.dtype)
+    wd = np.full(td * cout * cin_pad, np.nan, dtype=w.dtype) if dgrad else None
+
+    def wino_val(tile_, co_l, cil, t12, mirror):
+        s_, q = t12 >> 2, t12 & 3
+        base = cil * 9 + (2 - s_ if mirror else s_)
+        g0 = tile_[co_l, base + (6 if mirror else 0)]
+        g1 = tile_[co_l, base + 3]
+        g2 = tile_[co_l, base + (0 if mirror else 6)]
+        return g0 if q == 0 else g2 if q == 3 else 0.5 * ((g0 + g1) + g2) if q == 1 else 0.5 * ((g0 - g1) + g2)
     tiles_ci = -(-cin_pad // ib)
     nblk = -(-cout // 16) * tiles_ci
     for bid in range(nblk):
@@ -52,18 +93,19 @@ def run_pack(w, cin_pad, ib, scale=None, dgrad=True):
                 base = ((c0 + rr) * cin + i0) * t
                 tile[rr, :rl] = wflat[base:base + rl]
         nq = ncp >> 2
-        for pr in range(t * nq):
+        for pr in range(tf * nq):
             tt, ql = pr // nq, pr % nq
             for lane in range(64):
                 co_l, e = lane >> 2, lane & 3
                 co, cil = c0 + co_l, ql * 4 + e
                 if co < cout:
-                    v = tile[co_l, cil * t + tt] * (scale[co] if scale is not None else 1.0) if cil < nci else 0.0
+                    src = wino_val(tile, co_l, cil, tt, False) if (wino & 1 and cil < nci) else tile[co_l, cil * t + tt] if cil < nci else 0.0
+                    v = src * (scale[co] if scale is not None else 1.0) if cil < nci else 0.0
                     idx = ((tt * (cin_pad >> 2) + (i0 >> 2) + ql) * cout + co) * 4 + e
                     assert np.isnan(wf[idx])
                     wf[idx] = v
         if dgrad:
-            for pr in range(t * 4):
+            for pr in range(td * 4):
                 tt, cq = pr >> 2, pr & 3
                 for c in range(ncp * 4):
                     cil, e = c >> 2, c & 3
@@ -72,7 +114,7 @@ def run_pack(w, cin_pad, ib, scale=None, dgrad=True):
                     if co < cout:
                         idx = ((tt * (cout >> 2) + (c0 >> 2) + cq) * cin_pad + i0 + cil) * 4 + e
                         assert np.isnan(wd[idx])
-                        wd[idx] = tile[co_l, cil * t + tt] if cil < nci else 0.0
+                        wd[idx] = 0.0 if cil >= nci else wino_val(tile, co_l, cil, tt, True) if wino & 2 else tile[co_l, cil * t + tt]
     return wf, wd, nblk
 
 
@@ -259,6 +301,10 @@ def run_conv_s1(p, x, wpk, y, bias=None, res=None, bn=None):
     bn = (out | None, src, mean, invstd): the fused BatchNorm-backward epilogue (BpbS1BnBwd) -- the partials are then
     (sum G, sum G * xhat) with G = y where out > 0.  p.xr: the XCD-aware block -> tile map."""
     R, T, PAD = p.R, p.R * p.R, p.R // 2
+    wino = bool(getattr(p, 'wino', 0))
+    if wino:      # vertical F(2,3) form: 12 weight taps [column tap][position], a wave row = a PAIR of pixels (rows 2h, 2h + 1)
+        assert (p.R, p.S, p.mt_r, p.CK, p.wflip) == (3, 1, 2, 8, 0) and p.lTH >= 1 and not p.tstore
+        T = 12
     ti_n, th_n, tw_n = 1 << p.lTI, 1 << p.lTH, 1 << p.lTW
     mt_pix = ti_n * th_n * tw_n
     ntc = (32 * p.nt) << p.lwn
@@ -292,6 +338,7 @@ def run_conv_s1(p, x, wpk, y, bias=None, res=None, bn=None):
         ta = t2 - tn * p.tiles_a
         n0, a0, b0 = tn << p.lTI, ta << p.lTH, tb << p.lTW
         acc = np.zeros((mt_pix, ntc))
+        accw = np.zeros((4, mt_pix // 2, ntc))
         for cb in range(0, cin, ck):
             # ---- DMA image of this chunk: halo slots then weight slots (floats)
             halo = np.zeros(halo_pad * 4)
@@ -319,6 +366,22 @@ def run_conv_s1(p, x, wpk, y, bias=None, res=None, bn=None):
                     off = ((widx * cin4 + q) * cout + co) * 16 + (cb // 4) * cout * 16
                     assert off + 16 <= p.w_bytes
                     wts[bi * 4:bi * 4 + 4] = wpk[off // 4:off // 4 + 4]
+            if wino:
+                # pair p (column fastest, then pair row, then image): input rows 2h - 1 .. 2h + 2 = halo rows 2 * th2 + r
+                pr_ = np.arange(mt_pix // 2)
+                tw, th2, ti = pr_ & (tw_n - 1), (pr_ >> p.lTW) & ((th_n >> 1) - 1), pr_ >> (p.lTW + p.lTH - 1)
+                pixw = ((ti * p.HH + 2 * th2) * p.HW + tw) * ld
+                for s_ in range(3):
+                    for half in range(2):
+                        for e in range(4):
+                            d = [halo[pixw + (r_ * p.HW + s_) * ld + half * 4 + e] for r_ in range(4)]
+                            assert max(int((pixw + (3 * p.HW + s_) * ld + half * 4 + e).max()), 0) < halo_slots * 4
+                            v = [d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]]
+                            for q in range(4):
+                                bo = ((s_ * 4 + q) * 2 + half) * ntc * 4
+                                b = wts[bo + np.arange(ntc) * 4 + e]
+                                accw[q] += np.outer(v[q], b)
+                continue
             # ---- MFMA loop addressing: pixel m reads A at pixoff + ldsoff (+16 for the upper k half), column n reads B
             m = np.arange(mt_pix)
             tw, th, ti = m & (tw_n - 1), (m >> p.lTW) & (th_n - 1), m >> (p.lTW + p.lTH)
@@ -343,8 +406,16 @@ def run_conv_s1(p, x, wpk, y, bias=None, res=None, bn=None):
                 it_j = 0 if wj else it_j
                 ldsoff += 8 + (stepj if wk else 0) + (stepi if wj else 0)
         # ---- epilogue
+        if wino:      # output transform; wave wm's sub-tile mt holds row 2 * th2 + mt of its 32 pairs
+            y0, y1 = (accw[0] + accw[1]) + accw[2], (accw[1] - accw[2]) - accw[3]
         for mm in range(mt_pix):
-            n, a, b = n0 + (mm >> (p.lTW + p.lTH)), a0 + ((mm >> p.lTW) & (th_n - 1)), b0 + (mm & (tw_n - 1))
+            if wino:
+                wm_, mt_, j_ = mm // 64, (mm // 32) & 1, mm & 31
+                pp = wm_ * 32 + j_
+                n, a, b = (n0 + (pp >> (p.lTW + p.lTH - 1)), a0 + 2 * ((pp >> p.lTW) & ((th_n >> 1) - 1)) + mt_, b0 + (pp & (tw_n - 1)))
+                acc[mm] = (y1 if mt_ else y0)[pp]
+            else:
+                n, a, b = n0 + (mm >> (p.lTW + p.lTH)), a0 + ((mm >> p.lTW) & (th_n - 1)), b0 + (mm & (tw_n - 1))
             if not (n < p.N and a < p.H and b < p.W):
                 continue
             for c in range(ntc):

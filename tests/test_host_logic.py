@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_the_c_side():
     # sizes are asserted against values printed by the compiler (static_asserts live in csrc/abi_check.cpp)
     assert C.sizeof(nv.ConvProb) == 5 * 8 + 49 * 4 + 4 + 8 + 8     # padding before the bnf pointer, relu + tail padding
-    assert C.sizeof(nv.ConvS1Prob) == 8 * 8 + 24 * 4 + 9 * 4 + 5 * 4
+    assert C.sizeof(nv.ConvS1Prob) == 8 * 8 + 24 * 4 + 9 * 4 + 6 * 4 + 4      # + wino + tail padding
     assert C.sizeof(nv.WgradProb) == 3 * 8 + 27 * 4 + 5 * 4 + 4 + 4    # + ntw + tail padding
     assert C.sizeof(nv.PlanOp) == 4 + 11 * 4 + 4 * 4 + 2 * 8 + 12 * 8
 
@@ -108,8 +108,9 @@ def test_grouped_conv_policies_k_split_unpadded_halo_transposed_epilogue(monkeyp
     BatchNorm statistics use the transposed epilogue, data gradients and problems with statistics do not."""
     branches = [(64, 32, 32), (32, 16, 64), (16, 8, 128), (8, 4, 256)]
 
-    def build(nb, stats):
+    def build(nb, stats, wino=False):
         net = Net(torch.device('cpu'))
+        net.use_wino = wino
         net.fork(max(2, nb))
         for i, (h, w, c) in enumerate(branches[:nb]):
             net.set_slot(i)
@@ -129,7 +130,7 @@ def test_grouped_conv_policies_k_split_unpadded_halo_transposed_epilogue(monkeyp
         net.finalize(train_backward=stats)
         return net, [p for p, *_ in net.debug_convs if isinstance(p, nv.ConvS1Prob)]
 
-    net, probs = build(4, False)
+    net, probs = build(4, False)          # (the direct form: BPB_WINO=0)
     by_c = {p.Cin: p for p in probs}
     assert by_c[256].split and not any(by_c[c].split for c in (32, 64, 128))
     assert by_c[256].LD == by_c[256].CK and all(by_c[c].LD == by_c[c].CK + 4 for c in (32, 64, 128))
@@ -151,6 +152,21 @@ def test_grouped_conv_policies_k_split_unpadded_halo_transposed_epilogue(monkeyp
     dgrad = [p for p in probs_t if p.wflip]
     assert fwd and dgrad and all(p.tstore == 0 for p in fwd + dgrad)
     assert any(p.split for p in fwd) and any(p.split for p in dgrad)
+    # ---- the same module step in the F(2,3) form (the default, BPB_WINO=1): 256-pixel tiles of two-row wave tiles, 8-channel chunks, 12 taps,
+    # the deepest problem still splits its chunks over two workgroups, the halo is staged unpadded where that buys the third workgroup per CU
+    net_w, probs_w = build(4, True, wino=True)
+    assert len(probs_w) == 8 and all(p.wino == 1 and (p.mt_r, p.nt, p.lwn, p.CK, p.R, p.S, p.wflip, p.tstore) == (2, 1, 0, 8, 3, 1, 0, 0) for p in probs_w)
+    assert all((1 << (p.lTI + p.lTH + p.lTW)) == 256 and p.lTH >= 1 for p in probs_w)
+    lds_w = lambda p: 2 * (((1 << p.lTI) * p.HH * p.HW * (p.LD // 4) + 3) // 4 * 4 + 12 * 2 * 32) * 16
+    # three workgroups per CU up to 128 channels; the 8x4 maps of the 256-channel branch stage eight whole images (480 halo pixels) per
+    # tile: 55.3 KB even unpadded, 0.7 KB over a third of the CU -- a launch that contains it runs two per CU
+    assert all(lds_w(p) <= 160 * 1024 // 3 for p in probs_w if p.Cin <= 128), [lds_w(p) for p in probs_w]
+    assert all(lds_w(p) <= 79 * 1024 for p in probs_w)
+    by_cw = {p.Cin: p for p in probs_w[:4]}
+    assert by_cw[32].LD == 8 and by_cw[256].split and not any(by_cw[c].split for c in (32, 64, 128))
+    op = [o for o, m in zip(net_w.plan_train[0], net_w.plan_train[2]) if m['label'].startswith('conv_fwd')][0]
+    assert 'F(2,3)' in [m['label'] for m in net_w.plan_train[2] if m['label'].startswith('conv_fwd')][0]
+    assert op.i[0] == 4 and op.i[1] == 512 + 256 + 128 + 2 * 64
 
 
 @pytest.mark.parametrize('shape', [(64, 3, 7), (64, 3, 3), (32, 32, 3), (48, 24, 3), (256, 64, 1), (64, 256, 1), (36, 96, 1), (20, 8, 5)])
@@ -171,6 +187,14 @@ def test_weight_packing_tiles_write_every_packed_element_once(shape):
     assert np.array_equal(wf, emu.pack_fwd(w, cin_pad)) and np.array_equal(wd, emu.pack_dgrad(w, cin_pad))
     wfs, _, _ = emu.run_pack(w, cin_pad, ib, scale=scale, dgrad=False)
     assert np.array_equal(wfs, emu.pack_fwd(w * scale[:, None, None, None], cin_pad))
+    if k == 3 and cin % 8 == 0:      # the 12-tap F(2,3) packing of either side (BpbPackProb.wino bits 0 / 1), independently
+        for bits in (1, 2, 3):
+            wf, wd, _ = emu.run_pack(w, cin_pad, ib, wino=bits)
+            assert np.array_equal(wf, (emu.pack_fwd_wino if bits & 1 else emu.pack_fwd)(w, cin_pad))
+            assert np.array_equal(wd, (emu.pack_dgrad_wino if bits & 2 else emu.pack_dgrad)(w, cin_pad))
+        wfs, _, _ = emu.run_pack(w, cin_pad, ib, scale=scale, dgrad=False, wino=1)
+        ref = emu.pack_fwd_wino(w, cin_pad).reshape(12, cin_pad // 4, cout, 4) * scale[None, None, :, None]
+        assert np.array_equal(wfs, ref.reshape(-1).astype(np.float32))
 
 
 @pytest.mark.parametrize('r, hi, wi, nblk', [(3, 20, 36, 8), (7, 20, 36, 3), (7, 33, 17, 6), (3, 16, 32, 2)])
@@ -280,7 +304,9 @@ def test_conv_descriptors_forward_dgrad_wgrad(case):
                           else emu.run_conv)(pr, *a)
     assert isinstance(prob, nv.ConvS1Prob) == (stride in (1, 2) and k in (1, 3) and pad == k // 2 and cin % 8 == 0 and cout % 8 == 0)
     y = np.zeros((n, node.y.H, node.y.W, cout))
-    stats = run(prob, x_nhwc, emu.pack_fwd(wt.numpy(), cpad), y)
+    is_wino = lambda pr: isinstance(pr, nv.ConvS1Prob) and bool(pr.wino)
+    assert is_wino(prob) == (k == 3 and stride == 1 and pad == 1 and cin % 8 == 0 and cout % 8 == 0 and h >= 2 and h * w >= 32), 'F(2,3) selection'
+    stats = run(prob, x_nhwc, (emu.pack_fwd_wino if is_wino(prob) else emu.pack_fwd)(wt.numpy(), cpad), y)
     ref = F.conv2d(xin, wt, stride=stride, padding=pad).permute(0, 2, 3, 1).numpy()
     assert np.allclose(y, ref, atol=1e-9), 'forward geometry'
     assert np.allclose(stats[:, 0].sum(0), ref.sum((0, 1, 2)), atol=1e-8)
@@ -314,7 +340,8 @@ def test_conv_descriptors_forward_dgrad_wgrad(case):
             if first:
                 gx[:] = 0 if stride == 1 else gx
                 first = False
-            run(dp, gy.numpy(), emu.pack_dgrad(wt.numpy(), cpad), gx)
+            assert is_wino(dp) == is_wino(prob)
+            run(dp, gy.numpy(), (emu.pack_dgrad_wino if is_wino(dp) else emu.pack_dgrad)(wt.numpy(), cpad), gx)
         assert not np.isnan(gx).any(), 'dgrad classes do not cover every input pixel'
         assert np.allclose(gx, xr.grad.permute(0, 2, 3, 1).numpy(), atol=1e-9), 'dgrad geometry'
     # ---- weight gradient
@@ -432,7 +459,7 @@ def test_fused_batchnorm_backward_partials_ride_in_the_dgrad_descriptor(case):
     net.fuse([(cv2, 0)], True)
     net.finalize(train_backward=True)
     fused = [r for r in net.bwd if '+bn_bwd_partials' in r.label]
-    assert len(fused) == 1 and fused[0].desc.wflip == 1 and fused[0].desc.y == a1.grad.data_ptr()
+    assert len(fused) == 1 and (fused[0].desc.wflip == 1 or fused[0].desc.wino == 1) and fused[0].desc.y == a1.grad.data_ptr()
     labels = [r.label.split(' ')[0] for r in net.bwd]
     assert labels.count('bn_bwd_reduce') == 1 and labels.count('bn_bwd_finalize') == 2 and labels.count('bn_bwd_apply') == 2
     dp = fused[0].desc
@@ -447,7 +474,7 @@ def test_fused_batchnorm_backward_partials_ride_in_the_dgrad_descriptor(case):
     out1 = np.maximum((y1 - mean) * invstd, 0.0)                                     # (gamma 1, beta 0)
     gy2 = mk(n, cv2.y.H, cv2.y.W, c2).numpy()
     ga1 = np.zeros((n, h, w, c1))
-    stats = emu.run_conv_s1(dp, gy2, emu.pack_dgrad(w2.numpy(), c1), ga1, bn=(out1, y1, mean, invstd))
+    stats = emu.run_conv_s1(dp, gy2, (emu.pack_dgrad_wino if dp.wino else emu.pack_dgrad)(w2.numpy(), c1), ga1, bn=(out1, y1, mean, invstd))
     ref = torch.nn.grad.conv2d_input((n, c1, h, w), w2, torch.from_numpy(gy2).permute(0, 3, 1, 2), padding=k // 2).permute(0, 2, 3, 1).numpy()
     assert np.allclose(ga1, ref, atol=1e-9)
     gm = ref * (out1 > 0)
