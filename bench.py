@@ -349,6 +349,10 @@ def roofline(model, plan):
         # rocprofv3 summary profiles/*_bench_kernel_stats_one_stream.csv); frac_in_step: the same FLOPs over the kernel's average
         # duration inside the two-stream step (profiles/*_bench_kernel_stats.csv), where it shares the chip with the weight gradients
         r['frac_alone'] = r['frac']
+        if sym.endswith(',true>'):      # the F(2,3) form of bpb_conv_s1: `achieved` counts the convolution's (direct-form) FLOPs, SURVEY 8d
+            r['algorithm'] = ('vertical F(2,3): 48 MFMAs per 8-channel chunk and wave where the direct form issues 72 -- the matrix pipe itself '
+                              'runs at 2/3 of `achieved`')
+            r['mfma_issued_frac_of_peak'] = r['frac'] * 2.0 / 3.0
         us, src = in_step_duration(sym)
         r['frac_in_step'] = (dom['flops'] / dom['launches'] / (us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS) if us else None
         r['frac_in_step_source'] = src
@@ -632,6 +636,8 @@ def main():
                    'host_loop_ms_per_step_with_queue_backpressure': 1e3 * host_enqueue / args.steps,
                    'host_loop_ms_per_step_min_over_ranks': 1e3 * (host_enqueue_min if multi else host_enqueue) / args.steps,
                    'host_fraction_of_step_before_choosing_the_launch_mode': host_bound, 'launch_mode_probe': choice,
+                   'conv3x3_stride1': ('F(2,3): forward and data gradient as vertical minimal filtering, 2/3 of the MFMAs of the direct form, fp32 (BPB_WINO=0: direct)'
+                                       if next(iter(model._plans.values())).net.use_wino else 'direct'),
                    'k_split': k_split, 'taped_step': eng.fused_reason is None, 'taped_step_not_used_because': eng.fused_reason,
                    'host_cores_per_rank': len(pinned) if pinned else host_cores(),
                    'backbone_launches_per_step': sum(p_[1] for p_ in (next(iter(model._plans.values())).net.plan_train,

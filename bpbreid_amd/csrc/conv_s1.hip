@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob
             const int hc = hp - M24(t, HWd);
             const unsigned ti = s1_fdiv(t, HH, P.magic_hh);
             const int hr = t - M24(ti, HH);
-            const int n = n0 + (int)ti, ih = a0 * P.S + hr - PAD, iw = b0 * P.S + hc - PAD;
+            const int n = n0 + (int)ti, ih = a0 * P.S + hr - PAD, iw = b0 * P.S + hc - (P.nocol ? 0 : PAD);
             if (idx < halo_slots && v < qn && n < P.N && (unsigned)ih < (unsigned)P.Hi && (unsigned)iw < (unsigned)P.Wi)
                 vo = ((M24(M24(n, P.Hi) + ih, P.Wi) + iw) * (unsigned)Cin + v * 4) * 4u;
         }
@@ -225,11 +225,22 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob
     dma_issue(cbase * CK, 0);
     S1_TR(12);                                 // (first chunk's DMA issued)
     if constexpr (WINO) {
+        // nocol (a tile that spans the whole image row, staged WITHOUT the two padding columns: the 8x4 maps of the deepest branch are
+        // eight images of 10 x 6 halo pixels otherwise, 0.7 KB over a third of the CU's LDS): column tap s reads halo column tw + s - 1, and
+        // the two wrap-arounds (tap 0 of column 0, tap 2 of the last column: the neighbouring row's pixels) are replaced by zeros
+        const int cshift = P.nocol ? -1 : 0;
+        bool wrapL = false, wrapR = false;
+        {
+            int tw, th, ti;
+            tile_pix(0, l31, tw, th, ti);
+            wrapL = P.nocol && tw == 0;
+            wrapR = P.nocol && tw == TWm;
+        }
         int aw[3][4];         // LDS byte offset of this lane's input pixel (column tap s, input row 2h - 1 + r), current buffer
 #pragma unroll
         for (int s_ = 0; s_ < 3; ++s_)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) aw[s_][r] = pixoff[0] + (r * HWd + s_) * LD * 4;
+            for (int r = 0; r < 4; ++r) aw[s_][r] = pixoff[0] + (r * HWd + s_ + cshift) * LD * 4;
 #ifndef S1_WINO_TWOLVL
 #define S1_WINO_TWOLVL 0
 #endif
@@ -255,10 +266,20 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob
             for (int r = 0; r < 4; ++r) raw[r] = *(const f32x4*)(lds + aw[0][r]);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) fb[0][nt] = *(const f32x4*)(lds + bptr + nt * 512);
-            V[0] = raw[0] - raw[2];
-            V[1] = raw[1] + raw[2];
-            V[2] = raw[2] - raw[1];
-            V[3] = raw[1] - raw[3];
+            auto make_v = [&](int s_) {
+                V[0] = raw[0] - raw[2];
+                V[1] = raw[1] + raw[2];
+                V[2] = raw[2] - raw[1];
+                V[3] = raw[1] - raw[3];
+                if (P.nocol && s_ != 1) {                 // (selects, not products: the wrapped reads may hold anything)
+                    const bool z = s_ == 0 ? wrapL : wrapR;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) V[q][i] = z ? 0.f : V[q][i];
+                }
+            };
+            make_v(0);
 #pragma unroll
             for (int j = 0; j < 12; ++j) {
                 const int s_ = j >> 2, q = j & 3;
@@ -280,12 +301,7 @@ __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob
                         else acc[q][nt] = MFMA32(V[q][i], fb[j & 1][nt][i], acc[q][nt]);
                     }
                 __builtin_amdgcn_sched_barrier(0);
-                if (q == 3 && s_ + 1 < 3) {
-                    V[0] = raw[0] - raw[2];
-                    V[1] = raw[1] + raw[2];
-                    V[2] = raw[2] - raw[1];
-                    V[3] = raw[1] - raw[3];
-                }
+                if (q == 3 && s_ + 1 < 3) make_v(s_ + 1);
             }
             const int delta = (c & 1) ? -bufbytes : bufbytes;
 #pragma unroll
@@ -760,7 +776,8 @@ int bpb_conv_s1(const BpbConvS1Prob* d_probs, const BpbConvS1Prob* h_probs, int 
         BPB_REQUIRE(p.res == nullptr || p.accumulate == 0, "bpb_conv_s1: a residual operand excludes the accumulate mode");
         BPB_REQUIRE(p.bnb == nullptr || (p.stats != nullptr && p.relu == 0 && p.res == nullptr && p.bias == nullptr),
                     "bpb_conv_s1: the BatchNorm-backward partials need `stats` and a plain (or accumulating) data-gradient epilogue");
-        BPB_REQUIRE(p.HH == ((1 << p.lTH) - 1) * p.S + R && p.HW == ((1 << p.lTW) - 1) * p.S + R, "bpb_conv_s1: halo extent mismatch");
+        BPB_REQUIRE(p.nocol == 0 || (p.nocol == 1 && p.wino == 1 && p.tiles_b == 1), "bpb_conv_s1: a halo without padding columns is for F(2,3) tiles that span the image row");
+        BPB_REQUIRE(p.HH == ((1 << p.lTH) - 1) * p.S + R && p.HW == ((1 << p.lTW) - 1) * p.S + (p.nocol ? 1 : R), "bpb_conv_s1: halo extent mismatch");
         BPB_REQUIRE(p.H == (p.Hi + 2 * (R / 2) - R) / p.S + 1 && p.W == (p.Wi + 2 * (R / 2) - R) / p.S + 1 && (p.S == 1 || p.wflip == 0),
                     "bpb_conv_s1: output %dx%d does not follow from input %dx%d (stride %d)", p.H, p.W, p.Hi, p.Wi, p.S);
         BPB_REQUIRE(p.x_bytes > 0 && p.w_bytes > 0 && p.y_bytes > 0 && p.x_bytes < 0x80000000u && p.w_bytes < 0x80000000u &&

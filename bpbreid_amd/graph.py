@@ -45,6 +45,7 @@ TUNE = {
     'wgrad16_tpb': 4,
     'wgrad1x1_blocks': 512,
     'wgrad_reduce_lsl_big': 4,   # log2 of the split lanes per block of a slab reduce over more than 32 slabs
+    'wino_nocol': 1,             # ... and without the two padding columns where the tile spans the image row (the 8x4 maps)
     'wino_ld8': 1,               # F(2,3) problems stage their halo unpadded where that buys the third workgroup per CU
     'wgrad_reduce_vec': 1,       # slab reduce with 16-byte lanes (0: the 4-byte form, profiles/r05_ab_wgrad_reduce_vec.txt)
     'conv_c4_blocks': 512,       # stem forward: workgroups (each walks a contiguous range of 8 x 16-pixel tiles; two per CU)
@@ -500,8 +501,17 @@ class Net:
         lds_of = lambda ld_: 2 * ((ti * hh * hw * (ld_ // 4) + 3) // 4 * 4 + tw_taps * (ck // 4) * ntc) * 16
         if lds_of(ck + 4) > quarter >= lds_of(ck) and self.s1_nopad:
             p.LD = ck
-        if is_w and TUNE['wino_ld8'] and lds_of(ck + 4) > 53 * 1024 >= lds_of(ck):
-            p.LD = ck                 # the F(2,3) tiles (256 pixels): unpadded they fit three to a CU
+        if is_w and TUNE['wino_ld8']:
+            # the F(2,3) tiles (256 pixels) three to a CU: the first of (padded pixels, unpadded pixels, unpadded and -- where the tile spans
+            # the image row -- without the two padding columns: `nocol`, csrc/conv_s1.hip) that fits a third of the CU's LDS
+            third = 160 * 1024 // 3
+            lds_w = lambda ld_, hw_: 2 * ((ti * hh * hw_ * (ld_ // 4) + 3) // 4 * 4 + tw_taps * (ck // 4) * ntc) * 16
+            forms = [(ck + 4, hw, 0), (ck, hw, 0)] + ([(ck, tw, 1)] if (tw >= w and TUNE['wino_nocol']) else [])
+            for ld_, hw_, nocol_ in forms:
+                if lds_w(ld_, hw_) <= third:
+                    p.LD, p.HW, p.nocol, hw = ld_, hw_, nocol_, hw_
+                    break
+            lds_of = lambda ld_: lds_w(ld_, hw)
         p.tiles_a, p.tiles_b = _cdiv(h, th), _cdiv(w, tw)
         p.n_mtiles = _cdiv(n, ti) * p.tiles_a * p.tiles_b
         p.n_ntiles = _cdiv(cout, ntc)
@@ -715,7 +725,7 @@ class Net:
                        work=float(prob.Cin * (prob.NTC // 32)))
         if isinstance(prob, ConvS1Prob):
             kind, key = nv.OP_CONV_S1, ('s1', prob.nt, prob.mt_r, prob.R, prob.CK, prob.wino)
-            variant = 'bpb_conv_s1_kernel<%d,%d,%d,%d%s>' % (prob.nt, prob.mt_r, prob.R, prob.CK // 8, ',F(2,3)' if prob.wino else '')
+            variant = 'bpb_conv_s1_kernel<%d,%d,%d,%d,%s>' % (prob.nt, prob.mt_r, prob.R, prob.CK // 8, 'true' if prob.wino else 'false')     # (true: the F(2,3) form)
             npix, taps, cin_in = prob.N * prob.H * prob.W, prob.R * prob.R, prob.N * prob.H * prob.W * prob.Cin
             blocks = prob.n_mtiles * prob.n_ntiles
         else:

@@ -41,7 +41,7 @@ class ConvS1Prob(C.Structure):
             'N', 'H', 'W', 'Cin', 'Cout', 'R', 'lTI', 'lTH', 'lTW', 'HH', 'HW', 'CK', 'LD', 'tiles_a', 'tiles_b', 'n_mtiles',
             'n_ntiles', 'blk_begin', 'lwn', 'mt_r', 'nt', 'accumulate', 'relu', 'wflip')] + [
         (n, C.c_uint) for n in ('x_bytes', 'w_bytes', 'y_bytes', 'magic_spp', 'magic_hw', 'magic_hh', 'magic_nt', 'magic_tb',
-                                'magic_ta')] + [(n, C.c_int) for n in ('S', 'Hi', 'Wi', 'xr', 'tstore', 'wino')]
+                                'magic_ta')] + [(n, C.c_int) for n in ('S', 'Hi', 'Wi', 'xr', 'tstore', 'wino', 'nocol')]
 
 
 class ConvS1wProb(C.Structure):

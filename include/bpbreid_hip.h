@@ -142,6 +142,8 @@ typedef struct BpbConvS1Prob {
     int wino;               // 1: vertical F(2,3) form (R = 3, S = 1, mt_r = 2, CK = 8, wflip = 0): w is the 12-tap packing
                             // [column tap s][position 0..3][Cin/4][Cout][4] of bpb_pack_weights (BpbPackProb.wino), 48 instead of 72 MFMAs
                             // per chunk and wave; the pairs of a wave tile are rows (2h, 2h + 1): lTH >= 1
+    int nocol;              // 1 (wino, tiles_b == 1): the tile is staged without its two padding columns, HW = 2^lTW -- the kernel shifts
+                            // the column taps and zeroes the two that would wrap into the neighbouring row
 } BpbConvS1Prob;
 
 /* Pointwise (1x1, stride 1) convolution as a plain [P pixels x Cin] . [Cin x Cout] GEMM on NHWC tensors (csrc/conv_pw.hip):

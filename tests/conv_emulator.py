@@ -309,7 +309,9 @@ def run_conv_s1(p, x, wpk, y, bias=None, res=None, bn=None):
     mt_pix = ti_n * th_n * tw_n
     ntc = (32 * p.nt) << p.lwn
     assert mt_pix == (4 >> p.lwn) * p.mt_r * 32 and p.n_ntiles == -(-p.Cout // ntc)
-    assert p.HH == (th_n - 1) * p.S + R and p.HW == (tw_n - 1) * p.S + R and p.LD in (p.CK, p.CK + 4)
+    nocol = bool(getattr(p, 'nocol', 0))          # F(2,3) tile spanning the image row, staged without its two padding columns
+    assert not nocol or (wino and p.tiles_b == 1)
+    assert p.HH == (th_n - 1) * p.S + R and p.HW == (tw_n - 1) * p.S + (1 if nocol else R) and p.LD in (p.CK, p.CK + 4)
     cin, cout, ld, ck = p.Cin, p.Cout, p.LD, p.CK
     cin4, qn, spp = cin // 4, ck // 4, ld // 4
     npix = ti_n * p.HH * p.HW
@@ -349,7 +351,7 @@ def run_conv_s1(p, x, wpk, y, bias=None, res=None, bn=None):
                 hc = hp - t * p.HW
                 ti = _fdiv(t, p.HH, p.magic_hh)
                 hr = t - ti * p.HH
-                n, ih, iw = n0 + ti, a0 * p.S + hr - PAD, b0 * p.S + hc - PAD
+                n, ih, iw = n0 + ti, a0 * p.S + hr - PAD, b0 * p.S + hc - (0 if nocol else PAD)
                 if idx < halo_slots and v < qn and n < p.N and 0 <= ih < p.Hi and 0 <= iw < p.Wi:
                     off = (((n * p.Hi + ih) * p.Wi + iw) * cin + v * 4) * 4 + cb * 4
                     assert off % 16 == 0 and off + 16 <= p.x_bytes
@@ -371,12 +373,17 @@ def run_conv_s1(p, x, wpk, y, bias=None, res=None, bn=None):
                 pr_ = np.arange(mt_pix // 2)
                 tw, th2, ti = pr_ & (tw_n - 1), (pr_ >> p.lTW) & ((th_n >> 1) - 1), pr_ >> (p.lTW + p.lTH - 1)
                 pixw = ((ti * p.HH + 2 * th2) * p.HW + tw) * ld
+                cshift = -1 if nocol else 0
                 for s_ in range(3):
+                    # nocol: the wrap-arounds (tap 0 of column 0, tap 2 of the last column) read anything (poisoned here) and are zeroed
+                    wrap = (tw == 0) if (nocol and s_ == 0) else (tw == tw_n - 1) if (nocol and s_ == 2) else np.zeros(len(tw), bool)
                     for half in range(2):
                         for e in range(4):
-                            d = [halo[pixw + (r_ * p.HW + s_) * ld + half * 4 + e] for r_ in range(4)]
-                            assert max(int((pixw + (3 * p.HW + s_) * ld + half * 4 + e).max()), 0) < halo_slots * 4
+                            idxs = [pixw + (r_ * p.HW + s_ + cshift) * ld + half * 4 + e for r_ in range(4)]
+                            assert all(int(ix[~wrap].max()) < halo_slots * 4 and int(ix[~wrap].min()) >= 0 for ix in idxs)
+                            d = [np.where(wrap, np.nan, halo[np.clip(ix, 0, halo_pad * 4 - 1)]) for ix in idxs]
                             v = [d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]]
+                            v = [np.where(wrap, 0.0, v_) for v_ in v]
                             for q in range(4):
                                 bo = ((s_ * 4 + q) * 2 + half) * ntc * 4
                                 b = wts[bo + np.arange(ntc) * 4 + e]

@@ -200,6 +200,8 @@ CONV_CASES = [
     (2, 24, 8, 96, 48, 1, 1, 0),
     (5, 2, 1, 8, 8, 3, 1, 1),
     (3, 5, 3, 16, 40, 3, 1, 1),
+    (24, 7, 3, 32, 32, 3, 1, 1),       # F(2,3) form on eight-image tiles staged without padding columns, ragged in both directions
+    (3, 9, 7, 16, 40, 3, 1, 1),        # F(2,3) form, odd height and width, Cout not a multiple of 32
 ]
 
 
@@ -373,16 +375,18 @@ def test_pointwise_conv_kernel_epilogues(cin, cout):
         assert rel_err(rows[1], (G * (src.double() - mean.double()) * invstd.double()).sum(0)) < 2e-5
 
 
+@pytest.mark.parametrize('wino', [True, False])
 @pytest.mark.parametrize('ratio', ['2', '8'])
-def test_conv_s1_k_split_across_workgroups(ratio, monkeypatch):
+def test_conv_s1_k_split_across_workgroups(ratio, wino, monkeypatch):
     """A grouped launch whose deep problems take two workgroups per tile (BpbS1Split: first half of the channel chunks ->
     hand-over through memory -> second half + epilogue), forward with BatchNorm partials, data and weight gradients, twice (the
     hand-over flags re-arm themselves)."""
     monkeypatch.setenv('BPB_S1_SPLIT_RATIO', ratio)
     g = torch.Generator().manual_seed(77)
-    shapes = [(24, 12, 16, 16), (12, 6, 64, 64), (9, 5, 128, 32), (6, 3, 256, 256)]     # (H, W, Cin, Cout)
+    shapes = [(24, 12, 16, 16), (12, 6, 64, 64), (9, 5, 128, 32), (8, 4, 256, 256)]     # (H, W, Cin, Cout)
     n = 6
     net = Net(DEV)
+    net.use_wino = wino                    # both forms of the 3x3 kernel hand their accumulators over the same way
     net.fork(len(shapes))
     items = []
     for i, (h, w, cin, cout) in enumerate(shapes):
@@ -404,6 +408,7 @@ def test_conv_s1_k_split_across_workgroups(ratio, monkeypatch):
     net.finalize(train_backward=True)
     probs = [p for p, *_ in net.debug_convs if isinstance(p, nv.ConvS1Prob)]
     nsplit = sum(1 for p in probs if p.split)
+    assert all(bool(p.wino) == wino for p in probs)
     assert nsplit >= (4 if ratio == '2' else 2), 'no problem was split (forward + data gradient)'
     grads = [torch.randn(it[5].buf.shape, generator=g) for it in items]
     for rep in range(2):

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_the_c_side():
     # sizes are asserted against values printed by the compiler (static_asserts live in csrc/abi_check.cpp)
     assert C.sizeof(nv.ConvProb) == 5 * 8 + 49 * 4 + 4 + 8 + 8     # padding before the bnf pointer, relu + tail padding
-    assert C.sizeof(nv.ConvS1Prob) == 8 * 8 + 24 * 4 + 9 * 4 + 6 * 4 + 4      # + wino + tail padding
+    assert C.sizeof(nv.ConvS1Prob) == 8 * 8 + 24 * 4 + 9 * 4 + 7 * 4          # (+ wino, nocol)
     assert C.sizeof(nv.WgradProb) == 3 * 8 + 27 * 4 + 5 * 4 + 4 + 4    # + ntw + tail padding
     assert C.sizeof(nv.PlanOp) == 4 + 11 * 4 + 4 * 4 + 2 * 8 + 12 * 8
 
@@ -90,6 +90,8 @@ CONV_CASES = [
     (2, 5, 20, 32, 32, 3, 1, 1),
     (4, 4, 2, 64, 16, 1, 1, 0),
     (1, 16, 16, 8, 136, 3, 1, 1),
+    (40, 8, 4, 8, 8, 3, 1, 1),         # F(2,3) tiles of eight whole 8x4 images (+ a ragged one): staged without padding columns (nocol)
+    (24, 7, 3, 8, 16, 3, 1, 1),        # ... ragged in both directions (odd height: the last pair's second row is outside the image)
     (2, 16, 16, 16, 40, 3, 2, 1),      # stride-2 3x3: wgrad16 with a 17x17 staged image per 8x8 tile
     (3, 12, 8, 32, 16, 3, 2, 1),       # stride-2, 4-wide tiles (17x9 image), ragged rows, two images per tile
     (2, 9, 5, 64, 136, 1, 1, 0),       # 1x1 weight gradient kernel: 64 x 256 tile, ragged pixels and output channels
@@ -158,14 +160,14 @@ def test_grouped_conv_policies_k_split_unpadded_halo_transposed_epilogue(monkeyp
     assert len(probs_w) == 8 and all(p.wino == 1 and (p.mt_r, p.nt, p.lwn, p.CK, p.R, p.S, p.wflip, p.tstore) == (2, 1, 0, 8, 3, 1, 0, 0) for p in probs_w)
     assert all((1 << (p.lTI + p.lTH + p.lTW)) == 256 and p.lTH >= 1 for p in probs_w)
     lds_w = lambda p: 2 * (((1 << p.lTI) * p.HH * p.HW * (p.LD // 4) + 3) // 4 * 4 + 12 * 2 * 32) * 16
-    # three workgroups per CU up to 128 channels; the 8x4 maps of the 256-channel branch stage eight whole images (480 halo pixels) per
-    # tile: 55.3 KB even unpadded, 0.7 KB over a third of the CU -- a launch that contains it runs two per CU
-    assert all(lds_w(p) <= 160 * 1024 // 3 for p in probs_w if p.Cin <= 128), [lds_w(p) for p in probs_w]
-    assert all(lds_w(p) <= 79 * 1024 for p in probs_w)
+    # three workgroups per CU: the 8x4 maps of the 256-channel branch stage eight whole images per tile -- 55.3 KB even with unpadded
+    # pixels, 0.7 KB over a third of the CU; without the two padding columns (nocol) 45 KB
+    assert all(lds_w(p) <= 160 * 1024 // 3 for p in probs_w), [lds_w(p) for p in probs_w]
     by_cw = {p.Cin: p for p in probs_w[:4]}
     assert by_cw[32].LD == 8 and by_cw[256].split and not any(by_cw[c].split for c in (32, 64, 128))
+    assert (by_cw[256].nocol, by_cw[256].LD, by_cw[256].HW) == (1, 8, 4) and not any(by_cw[c].nocol for c in (32, 64, 128))
     op = [o for o, m in zip(net_w.plan_train[0], net_w.plan_train[2]) if m['label'].startswith('conv_fwd')][0]
-    assert 'F(2,3)' in [m['label'] for m in net_w.plan_train[2] if m['label'].startswith('conv_fwd')][0]
+    assert ',true>' in [m['label'] for m in net_w.plan_train[2] if m['label'].startswith('conv_fwd')][0]      # (the F(2,3) variant)
     assert op.i[0] == 4 and op.i[1] == 512 + 256 + 128 + 2 * 64
 
 
@@ -306,6 +308,7 @@ def test_conv_descriptors_forward_dgrad_wgrad(case):
     y = np.zeros((n, node.y.H, node.y.W, cout))
     is_wino = lambda pr: isinstance(pr, nv.ConvS1Prob) and bool(pr.wino)
     assert is_wino(prob) == (k == 3 and stride == 1 and pad == 1 and cin % 8 == 0 and cout % 8 == 0 and h >= 2 and h * w >= 32), 'F(2,3) selection'
+    assert not is_wino(prob) or bool(prob.nocol) == (w <= 4), 'padding columns dropped where that buys the third workgroup per CU'
     stats = run(prob, x_nhwc, (emu.pack_fwd_wino if is_wino(prob) else emu.pack_fwd)(wt.numpy(), cpad), y)
     ref = F.conv2d(xin, wt, stride=stride, padding=pad).permute(0, 2, 3, 1).numpy()
     assert np.allclose(y, ref, atol=1e-9), 'forward geometry'
