@@ -50,7 +50,10 @@ __device__ unsigned long long* g_s1_trace = nullptr;
 // the four row-transformed filters g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2 of that column (packed as 12 "taps" [s][position] by
 // bpb_pack_weights) into four accumulators m0 .. m3; the two output rows are m0 + m1 + m2 and m1 - m2 - m3.  48 MFMAs per 8-channel
 // chunk for 64 pixels x 32 channels instead of 72; staging, epilogue and hand-over are those of the MT = 2 kernel (sub-tile 0 = the even
-// rows, sub-tile 1 = the odd rows of the pairs).  Round-off: at the level of the direct form (tests/test_wino_cpu.py).
+// rows, sub-tile 1 = the odd rows of the pairs).  Round-off: 1.7x (32 channels) to 3.3x (256 channels) the direct form's -- 4e-8 .. 1.2e-7 rms of
+// the largest output value (tools/wino_err.py, profiles/r05_f23_roundoff.txt): the three-term output sums of the transform, and position
+// chains of 3 * Cin products that are accumulated in one level (the chunk-sum level of the direct form costs 64 registers here = the third
+// wave per SIMD, 27.3 -> 28.7 ms per step).  BPB_WINO=0 (Net.use_wino) plans the direct form.
 template <int NT, int MT, int R, int KG, bool WINO = false>   // KG = 8-channel k-groups per tap and pipeline stage: channel chunk CK = 8 * KG
 __global__ __launch_bounds__(256, 2) void bpb_conv_s1_kernel(const BpbConvS1Prob* __restrict__ probs, BpbBlkBegins bb)
 {
