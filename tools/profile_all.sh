@@ -20,6 +20,11 @@ DB=$(find /tmp/profk1 -name "*.db" | head -1); python tools/rocprof_summary.py $
 # the bench line of the final build (cpu_baseline, eval, extra legs included), then the per-record timings
 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -1 $O/bench_default.json | cut -c1-200
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-eval --no-extra --dump-plan-timing $O/plan_timing.json > $O/bench_20steps.json 2>/dev/null
+# the same build with the 3x3 convolutions in the direct form (BPB_WINO=0): the A/B of the F(2,3) form, step / forward / round-off
+BPB_WINO=0 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-eval --dump-plan-timing $O/plan_timing_direct_form.json > $O/ab_f23_off_bench.json 2>/dev/null; tail -1 $O/ab_f23_off_bench.json | cut -c1-160
+python tools/plan_summary.py $O/plan_timing_direct_form.json > $O/plan_summary_direct_form.txt
+BPB_WINO=0 python tools/fwd_bench.py hrnet32 > $O/ab_f23_off_forward_only_hrnet32.json 2>/dev/null
+python tools/wino_err.py 2>/dev/null > $O/f23_roundoff.txt; tail -3 $O/f23_roundoff.txt | cut -c1-200
 python tools/plan_summary.py $O/plan_timing.json > $O/plan_summary.txt
 python tools/fwd_bench.py hrnet32 > $O/forward_only_hrnet32.json 2>/dev/null; tail -1 $O/forward_only_hrnet32.json | cut -c1-300
 python tools/fwd_bench.py resnet50 > $O/forward_only_resnet50.json 2>/dev/null
@@ -49,4 +54,6 @@ probe() {
   echo "== bpb_conv_pw 64->256 at 64x32, batch 64"; probe pw "conv_pw" tools/conv_pmc.py 64 32 64 256 1 10; } > $O/pmc_sq.txt 2>&1
 # endurance: 300 steps of the two-stream schedule with the K-split hand-overs (bench.py's safety net reports a time-out; the loss must stay finite)
 python bench.py --steps 300 --warmup 5 $Q > $O/bench_300steps.json 2> $O/bench_300steps.err; tail -1 $O/bench_300steps.json | cut -c1-200
-timeout 900 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; tail -2 $O/pytest_gpu.txt
+timeout 1200 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; tail -2 $O/pytest_gpu.txt
+# gradient digests of the model goldens, both forms of the 3x3 kernel (written by tests/test_gpu_model.py)
+for f in gpurun_out/grad_parity_*.txt; do echo "$(basename $f .txt | sed 's/grad_parity_//'): $(head -1 $f | cut -c3-)"; done | sort > $O/f23_grad_parity.txt
