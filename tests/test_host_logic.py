@@ -788,7 +788,7 @@ def test_roofline_traffic_is_quoted_only_from_a_profile_of_this_build(monkeypatc
     bench = importlib.import_module('bench')
     from bpbreid_amd import build
     table = json.load(open(os.path.join(ROOT, bench.PMC_FILE)))
-    got = bench.pmc_traffic('void bpb_conv_s1_kernel<1, 1, 3, 1>(BpbConvS1Prob const*, BpbBlkBegins)')
+    got = bench.pmc_traffic('void bpb_conv_s1_kernel<1, 2, 3, 1, true>(BpbConvS1Prob const*, BpbBlkBegins)')
     if table['_build']['source_id'] == build.source_id():
         assert got['traffic'] and got['traffic'] > 5e7 and build.source_id() in got['traffic_source']
     else:
@@ -797,7 +797,7 @@ def test_roofline_traffic_is_quoted_only_from_a_profile_of_this_build(monkeypatc
         warnings.warn('profiles: PMC passes are from another build -- rerun tools/profile_all.sh')
         assert got['traffic'] is None and 'not quoted' in got['traffic_source']
     monkeypatch.setattr(build, 'source_id', lambda: 'ffffffffffffffff')
-    stale = bench.pmc_traffic('void bpb_conv_s1_kernel<1, 1, 3, 1>(BpbConvS1Prob const*, BpbBlkBegins)')
+    stale = bench.pmc_traffic('void bpb_conv_s1_kernel<1, 2, 3, 1, true>(BpbConvS1Prob const*, BpbBlkBegins)')
     assert stale['traffic'] is None and 'not quoted' in stale['traffic_source']
 
 
