@@ -375,6 +375,48 @@ def test_pointwise_conv_kernel_epilogues(cin, cout):
         assert rel_err(rows[1], (G * (src.double() - mean.double()) * invstd.double()).sum(0)) < 2e-5
 
 
+@pytest.mark.parametrize('shape', [(16, 32, 16, 32, 32), (16, 16, 8, 128, 128), (64, 8, 4, 256, 256)])
+def test_f23_form_round_off_next_to_the_direct_form(shape):
+    """The price of the F(2,3) form of the 3x3 kernel, asserted: forward and data gradient of one convolution (post-ReLU input, BatchNorm behind
+    it) against fp64 in BOTH forms.  Measured (tools/wino_err.py, profiles/r05_f23_roundoff.txt): direct 2.3-3.2e-8 rms of the largest reference
+    value, F(2,3) 3.7e-8 (32 channels) .. 9.4e-8 forward / 1.2e-7 data gradient (256 channels), x1.5 .. x3.4.  Bounds: 1.5e-7 rms, 1.2e-6 max,
+    at most 4.5x the direct form's rms -- a chunk-order or packing mistake is orders of magnitude above them, a lost accumulation level is not."""
+    n, h, w, cin, cout = shape
+    res = {}
+    for wino in (False, True):
+        g = torch.Generator().manual_seed(7)
+        x = torch.relu(torch.randn(n, cin, h, w, generator=g))
+        wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+        gr = torch.randn(n, h, w, cout, generator=g)
+        net = Net(DEV)
+        net.use_wino = wino
+        xa = Act(net, n, h, w, cin)
+        xa.needs_grad = True
+        xa.buf.copy_(nhwc(x))
+        wp = wt.to(DEV)
+        wp.grad = torch.zeros_like(wp)
+        gamma, beta = torch.ones(cout, device=DEV), torch.zeros(cout, device=DEV)
+        gamma.grad, beta.grad = torch.zeros_like(gamma), torch.zeros_like(beta)
+        node = net.conv(xa, wp, 1, 1, bn=(gamma, beta, torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV)))
+        out = net.fuse([(node, 0)], relu=False)
+        net.finalize(train_backward=True)
+        assert all(bool(p.wino) == wino for p, *_ in net.debug_convs if isinstance(p, nv.ConvS1Prob))
+        net.run(net.plan_train)
+        out.grad.copy_(gr)
+        net.run(net.plan_bwd)
+        torch.cuda.synchronize()
+        xr = x.double().requires_grad_(True)
+        yr = F.conv2d(xr, wt.double(), padding=1)
+        F.batch_norm(yr, None, None, training=True, eps=1e-5).backward(nchw(gr).double())
+        stat = lambda got, ref: (float((got.double().cpu() - ref).abs().max() / ref.abs().max()),
+                                 float((got.double().cpu() - ref).pow(2).mean().sqrt() / ref.abs().max()))
+        res[wino] = (stat(nchw(node.y.buf), yr.detach()), stat(nchw(xa.grad), xr.grad))
+    for k, what in enumerate(('forward', 'data gradient')):
+        (dmax, drms), (wmax, wrms) = res[False][k], res[True][k]
+        assert drms < 5e-8 and dmax < 5e-7, (what, 'direct form', dmax, drms)
+        assert wrms < 1.5e-7 and wmax < 1.2e-6 and wrms < 4.5 * drms, (what, 'F(2,3) form', wmax, wrms, drms)
+
+
 @pytest.mark.parametrize('wino', [True, False])
 @pytest.mark.parametrize('ratio', ['2', '8'])
 def test_conv_s1_k_split_across_workgroups(ratio, wino, monkeypatch):
